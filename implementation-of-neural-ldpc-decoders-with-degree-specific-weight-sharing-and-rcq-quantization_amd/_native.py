@@ -1,0 +1,131 @@
+"""
+ctypes binding of the C ABI in include/ldpc_hip.h (libldpc_hip.so, built from
+csrc/ by build_native()).
+
+There is NO CPU fallback: when the library is missing or no HIP device is
+usable every decode raises ``NativeEngineError``.  The host classes only add
+Python-side bookkeeping around these calls.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libldpc_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip.h")
+
+LDPC_F32, LDPC_F64 = 0, 1
+C2V_NMS, C2V_RCQ, C2V_OMS = 0, 1, 2
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off",       # the reference never fuses llr + alpha*sum
+               "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-pragma-once-outside-header"]
+
+
+class NativeEngineError(RuntimeError):
+    pass
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir."""
+    srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"), HEADER]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout + res.stderr)
+    if res.returncode != 0:
+        raise NativeEngineError("hipcc failed:\n" + res.stderr[-4000:])
+    return LIB_PATH
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("c2v_form", C.c_int32), ("iters", C.c_int32),
+                ("n_beta_slots", C.c_int32), ("beta", C.c_void_p), ("beta_slot", C.c_void_p),
+                ("n_alpha_slots", C.c_int32), ("alpha", C.c_void_p), ("alpha_slot", C.c_void_p),
+                ("n_levels", C.c_int32), ("n_quantizers", C.c_int32), ("thresholds", C.c_void_p),
+                ("q_of_iter", C.c_void_p),
+                ("n_oms_alpha_slots", C.c_int32), ("oms_alpha", C.c_void_p), ("oms_alpha_slot", C.c_void_p)]
+
+
+# every symbol include/ldpc_hip.h declares (tests check the library exports them all)
+EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
+           "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
+           "ldpc_decode", "ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_last_error", "ldpc_abi_version")
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen the engine; raises NativeEngineError (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeEngineError(
+                f"{LIB_NAME} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(hipcc --offload-arch=gfx950) -- there is no CPU fallback for the decode path")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise NativeEngineError(f"cannot load {LIB_PATH}: {e}") from e
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        lib.ldpc_graph_create.restype = C.c_int
+        lib.ldpc_graph_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp, vp]
+        lib.ldpc_graph_destroy.restype = None
+        lib.ldpc_graph_destroy.argtypes = [vp]
+        lib.ldpc_graph_info.restype = C.c_int
+        lib.ldpc_graph_info.argtypes = [vp, vp]
+        lib.ldpc_decoder_create.restype = C.c_int
+        lib.ldpc_decoder_create.argtypes = [C.POINTER(vp), vp, C.POINTER(DecoderDesc)]
+        lib.ldpc_decoder_set_weights.restype = C.c_int
+        lib.ldpc_decoder_set_weights.argtypes = [vp, vp, vp, vp, vp]
+        lib.ldpc_decoder_destroy.restype = None
+        lib.ldpc_decoder_destroy.argtypes = [vp]
+        lib.ldpc_decoder_workspace_bytes.restype = C.c_size_t
+        lib.ldpc_decoder_workspace_bytes.argtypes = [vp, i64]
+        lib.ldpc_decode.restype = C.c_int
+        lib.ldpc_decode.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.ldpc_debug_sweep.restype = C.c_int
+        lib.ldpc_debug_sweep.argtypes = [vp, i64, i32, i32, vp, C.c_size_t, vp]
+        lib.ldpc_debug_workspace_layout.restype = C.c_int
+        lib.ldpc_debug_workspace_layout.argtypes = [vp, i64, vp]
+        lib.ldpc_last_error.restype = C.c_char_p
+        lib.ldpc_last_error.argtypes = []
+        lib.ldpc_abi_version.restype = C.c_int
+        lib.ldpc_abi_version.argtypes = []
+        if lib.ldpc_abi_version() != 1:
+            raise NativeEngineError("libldpc_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ldpc_last_error().decode(errors="replace")
+        if rc == -3:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NativeEngineError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,518 @@
+// ldpc_hip.hip -- C ABI (include/ldpc_hip.h) over the gfx950 kernels in ldpc_kernels.hip.
+//
+// Host side only: handle lifetime, table upload, workspace carving and the launch
+// sequence of one decode.  Nothing here allocates or synchronises inside ldpc_decode
+// (graph-capturable); all work goes to the caller's stream.
+#include "ldpc_kernels.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+
+using namespace ldpc;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(LDPC_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+template <typename X>
+int upload(X **dst, const X *src, size_t count)
+{
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void **)dst, count * sizeof(X)));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(X), hipMemcpyHostToDevice));
+    return LDPC_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct ldpc_graph {
+    int device = 0;
+    int n = 0, m = 0, E = 0, max_dc = 0, max_dv = 0;
+    int *check_ptr = nullptr, *var_idx = nullptr, *var_ptr = nullptr, *csc_edge = nullptr;
+    GraphDev dev() const { return GraphDev{n, m, E, check_ptr, var_idx, var_ptr, csc_edge}; }
+};
+
+struct ldpc_decoder {
+    const ldpc_graph *g = nullptr;
+    int dtype = LDPC_F32, form = LDPC_C2V_NMS, T = 0;
+    int n_beta = 0, n_alpha = 0, n_levels = 0, n_quant = 0, n_oms_alpha = 0;
+    void *beta = nullptr, *alpha = nullptr, *oms_alpha = nullptr;   // device, dtype-typed [T][slots]
+    int *beta_slot = nullptr, *alpha_slot = nullptr, *oms_alpha_slot = nullptr;
+    float *thresholds = nullptr;   // device [Q][L]
+    float *lut = nullptr;          // device [Q][2L] signed reconstruction values
+    std::vector<int> q_of_iter;    // host
+    size_t elem() const { return dtype == LDPC_F64 ? 8 : 4; }
+};
+
+namespace {
+
+// tile width: 64 lanes x VEC codewords.  fp32: VEC 4 (16 B per lane) for real batches,
+// VEC 1 for latency-mode batches <= 64; fp64: VEC 2 / 1.
+int pick_vec(const ldpc_decoder *d, int64_t batch)
+{
+    if (batch <= 64) return 1;
+    return d->dtype == LDPC_F64 ? 2 : 4;
+}
+
+struct Workspace {
+    int vec = 0, tiles = 0;
+    char *llrT = nullptr, *v2c = nullptr, *c2v = nullptr, *postT = nullptr;
+    uint64_t *bitsT = nullptr, *done = nullptr;
+    int *iters = nullptr;
+    size_t total = 0;
+};
+
+Workspace carve(const ldpc_decoder *d, int64_t batch, void *base)
+{
+    Workspace w;
+    w.vec = pick_vec(d, batch);
+    const int W = 64 * w.vec;
+    w.tiles = (int)((batch + W - 1) / W);
+    if (w.tiles < 1) w.tiles = 1;
+    const size_t es = d->elem();
+    const size_t n = d->g->n, E = d->g->E, tw = (size_t)w.tiles * W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t o_llr = take(tw * n * es);
+    const size_t o_v2c = take(tw * std::max<size_t>(E, 1) * es);
+    const size_t o_c2v = take(tw * std::max<size_t>(E, 1) * (d->form == LDPC_C2V_RCQ ? 1 : es));
+    const size_t o_post = take(tw * n * es);
+    const size_t o_bits = take((size_t)w.tiles * n * w.vec * sizeof(uint64_t));
+    const size_t o_done = take((size_t)w.tiles * w.vec * sizeof(uint64_t));
+    const size_t o_it = take(tw * sizeof(int));
+    w.total = off;
+    if (base) {
+        char *b = (char *)base;
+        w.llrT = b + o_llr; w.v2c = b + o_v2c; w.c2v = b + o_c2v; w.postT = b + o_post;
+        w.bitsT = (uint64_t *)(b + o_bits); w.done = (uint64_t *)(b + o_done); w.iters = (int *)(b + o_it);
+    }
+    return w;
+}
+
+// ---- launch helpers, one per kernel family ------------------------------------------------
+template <typename T, int VEC>
+int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
+{
+    const GraphDev g = d->g->dev();
+    const int cb = (g.m + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (cb == 0 || g.E == 0) return LDPC_OK;
+    const dim3 grid((unsigned)((size_t)w.tiles * cb)), block(kBlock);
+    const bool first = it == 0;
+    const T *src = first ? (const T *)w.llrT : (const T *)w.v2c;
+    const T *beta_row = (const T *)d->beta + (size_t)it * d->n_beta;
+    const T *oa_row = d->oms_alpha ? (const T *)d->oms_alpha + (size_t)it * d->n_oms_alpha : nullptr;
+    const float *thr = d->form == LDPC_C2V_RCQ ? d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels : nullptr;
+    const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_CN(FORM, FIRST)                                                                          \
+    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM, FIRST>), grid, block, 0, s, g, src, (void *)w.c2v,      \
+                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb)
+    if (d->form == LDPC_C2V_NMS) {
+        if (first) LDPC_CN(FORM_NMS, true); else LDPC_CN(FORM_NMS, false);
+    } else if (d->form == LDPC_C2V_OMS) {
+        if (first) LDPC_CN(FORM_OMS, true); else LDPC_CN(FORM_OMS, false);
+    } else {
+        if constexpr (sizeof(T) == 4) {
+            if (first) LDPC_CN(FORM_RCQ, true); else LDPC_CN(FORM_RCQ, false);
+        } else {
+            return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
+        }
+    }
+#undef LDPC_CN
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename T, int VEC>
+int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool use_done, hipStream_t s)
+{
+    const GraphDev g = d->g->dev();
+    const int vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid((unsigned)((size_t)w.tiles * vb)), block(kBlock);
+    const int row = it < d->T ? it : 0;     // T == 0: posterior-only pass, alpha unused
+    const T *alpha_row = (const T *)d->alpha + (size_t)row * d->n_alpha;
+    const bool codes = d->form == LDPC_C2V_RCQ;
+    const float *lut = codes ? d->lut + (size_t)d->q_of_iter[row] * 2 * d->n_levels : nullptr;
+    const int lut_size = codes ? 2 * d->n_levels : 0;
+    const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_VN(CODES, LAST)                                                                           \
+    hipLaunchKernelGGL((vn_sweep<T, VEC, CODES, LAST>), grid, block, 0, s, g, (const void *)w.c2v,      \
+                       (const T *)w.llrT, (T *)w.v2c, alpha_row, d->alpha_slot, lut, lut_size, w.bitsT, \
+                       (T *)w.postT, done, vb)
+    if (codes) {
+        if constexpr (sizeof(T) == 4) {
+            if (last) LDPC_VN(true, true); else LDPC_VN(true, false);
+        } else {
+            return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
+        }
+    } else {
+        if (last) LDPC_VN(false, true); else LDPC_VN(false, false);
+    }
+#undef LDPC_VN
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename T, int VEC>
+int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool early_stop, int32_t *bits,
+                void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed,
+                const Workspace &w, hipStream_t s)
+{
+    constexpr int W = 64 * VEC;
+    constexpr int JT = 128 / sizeof(T);
+    const GraphDev g = d->g->dev();
+    const int T_it = d->T;
+    const int vc = (g.n + JT - 1) / JT;
+
+    hipLaunchKernelGGL((transpose_in<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+                       (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+    {
+        const long long cnt = (long long)w.tiles * W;
+        hipLaunchKernelGGL((init_state<VEC>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, w.done,
+                           w.iters, (long long)batch, w.tiles, T_it);
+    }
+    HIP_TRY(hipGetLastError());
+
+    if (T_it == 0) {
+        // no iteration ran: c2v == 0, posterior = llr + 0  (loop skipped, ldpc_decoder.py:147-153)
+        const size_t c2v_bytes = (size_t)w.tiles * W * std::max(g.E, 1) * (d->form == LDPC_C2V_RCQ ? 1 : sizeof(T));
+        HIP_TRY(hipMemsetAsync(w.c2v, 0, c2v_bytes, s));
+        int rc = launch_vn<T, VEC>(d, w, 0, /*last=*/true, /*use_done=*/false, s);
+        if (rc) return rc;
+    }
+    for (int it = 0; it < T_it; ++it) {
+        int rc = launch_cn<T, VEC>(d, w, it, early_stop, s);
+        if (rc) return rc;
+        rc = launch_vn<T, VEC>(d, w, it, it == T_it - 1, early_stop, s);
+        if (rc) return rc;
+        if (early_stop) {
+            hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
+                               w.iters, it + 1, 1);
+        }
+    }
+    if (!early_stop) {
+        hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
+                           w.iters, T_it, 0);
+    } else if (T_it == 0) {
+        // reference: the loop never ran, success False, iterations 0 -> clear the (padding) latch bits
+        HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
+    }
+    HIP_TRY(hipGetLastError());
+
+    if (bits || posterior) {
+        hipLaunchKernelGGL((transpose_out<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+                           (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+    }
+    if (iterations || success || packed) {
+        long long threads = batch;
+        if (packed) threads = std::max<long long>(threads, std::min<long long>(batch * ((g.n + 7) / 8), 1ll << 22));
+        hipLaunchKernelGGL((finalize_out<VEC>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w.done,
+                           w.iters, w.bitsT, iterations, success, packed, (long long)batch, g.n);
+    }
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+template <typename T>
+int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool early_stop, int32_t *bits,
+                    void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed,
+                    const Workspace &w, hipStream_t s)
+{
+    switch (w.vec) {
+    case 1: return decode_impl<T, 1>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+    case 2:
+        if constexpr (sizeof(T) == 8)
+            return decode_impl<T, 2>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+        break;
+    case 4:
+        if constexpr (sizeof(T) == 4)
+            return decode_impl<T, 4>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+        break;
+    }
+    return fail(LDPC_ERR_ARG, "internal: bad tile width");
+}
+
+}  // namespace
+
+// =========================================================================================== C ABI
+extern "C" {
+
+const char *ldpc_last_error(void) { return g_err; }
+int ldpc_abi_version(void) { return LDPC_HIP_ABI_VERSION; }
+
+int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const int32_t *check_ptr,
+                      const int32_t *var_idx)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || m < 0 || E < 0 || !check_ptr || (E > 0 && !var_idx)) return fail(LDPC_ERR_ARG, "bad graph sizes");
+    if (check_ptr[0] != 0 || check_ptr[m] != E) return fail(LDPC_ERR_ARG, "check_ptr must span [0, E]");
+    std::vector<int> dv(n, 0);
+    int max_dc = 0;
+    for (int i = 0; i < m; ++i) {
+        const int a = check_ptr[i], b = check_ptr[i + 1];
+        if (b < a || b > E) return fail(LDPC_ERR_ARG, "check_ptr not monotone at check %d", i);
+        max_dc = std::max(max_dc, b - a);
+        for (int e = a; e < b; ++e) {
+            const int j = var_idx[e];
+            if (j < 0 || j >= n) return fail(LDPC_ERR_ARG, "var_idx[%d]=%d out of range", e, j);
+            if (e > a && var_idx[e - 1] >= j) return fail(LDPC_ERR_ARG, "edges of check %d not strictly ascending", i);
+            dv[j]++;
+        }
+    }
+    std::vector<int> var_ptr(n + 1, 0), csc(std::max(E, 1), 0), fill(n, 0);
+    int max_dv = 0;
+    for (int j = 0; j < n; ++j) {
+        var_ptr[j + 1] = var_ptr[j] + dv[j];
+        max_dv = std::max(max_dv, dv[j]);
+    }
+    // scanning CSR edges in order visits the checks of every variable in ascending order
+    for (int e = 0; e < E; ++e) {
+        const int j = var_idx[e];
+        csc[var_ptr[j] + fill[j]++] = e;
+    }
+    ldpc_graph *g = new (std::nothrow) ldpc_graph();
+    if (!g) return fail(LDPC_ERR_ARG, "out of host memory");
+    g->n = n; g->m = m; g->E = E; g->max_dc = max_dc; g->max_dv = max_dv;
+    if (hipGetDevice(&g->device) != hipSuccess) {
+        delete g;
+        return fail(LDPC_ERR_HIP, "no HIP device available");
+    }
+    int rc = upload(&g->check_ptr, check_ptr, (size_t)m + 1);
+    if (!rc) rc = upload(&g->var_idx, var_idx, (size_t)E);
+    if (!rc) rc = upload(&g->var_ptr, var_ptr.data(), (size_t)n + 1);
+    if (!rc) rc = upload(&g->csc_edge, csc.data(), (size_t)E);
+    if (rc) {
+        ldpc_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return LDPC_OK;
+}
+
+void ldpc_graph_destroy(ldpc_graph *g)
+{
+    if (!g) return;
+    DeviceGuard guard(g->device);
+    (void)hipFree(g->check_ptr); (void)hipFree(g->var_idx); (void)hipFree(g->var_ptr); (void)hipFree(g->csc_edge);
+    delete g;
+}
+
+int ldpc_graph_info(const ldpc_graph *g, int32_t out5[5])
+{
+    if (!g || !out5) return fail(LDPC_ERR_ARG, "NULL argument");
+    out5[0] = g->n; out5[1] = g->m; out5[2] = g->E; out5[3] = g->max_dc; out5[4] = g->max_dv;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc)
+{
+    if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!g || !desc) return fail(LDPC_ERR_ARG, "NULL argument");
+    if (desc->dtype != LDPC_F32 && desc->dtype != LDPC_F64) return fail(LDPC_ERR_ARG, "bad dtype");
+    if (desc->c2v_form < LDPC_C2V_NMS || desc->c2v_form > LDPC_C2V_OMS) return fail(LDPC_ERR_ARG, "bad c2v_form");
+    if (desc->iters < 0) return fail(LDPC_ERR_ARG, "iters < 0");
+    if (desc->n_beta_slots < 1 || desc->n_alpha_slots < 1 || !desc->beta || !desc->alpha ||
+        (g->E > 0 && !desc->beta_slot) || (g->n > 0 && !desc->alpha_slot))
+        return fail(LDPC_ERR_ARG, "weight tables missing");
+    for (int e = 0; e < g->E; ++e)
+        if (desc->beta_slot[e] < 0 || desc->beta_slot[e] >= desc->n_beta_slots) return fail(LDPC_ERR_ARG, "beta_slot[%d] out of range", e);
+    for (int j = 0; j < g->n; ++j)
+        if (desc->alpha_slot[j] < 0 || desc->alpha_slot[j] >= desc->n_alpha_slots) return fail(LDPC_ERR_ARG, "alpha_slot[%d] out of range", j);
+    // association orders restated on the device: torch.sum below its cascade level, np.sum one block
+    if (desc->dtype == LDPC_F32 && g->max_dv > 575) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 575 (fp32 sum order)", g->max_dv);
+    if (desc->dtype == LDPC_F64 && g->max_dv > 128) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 128 (fp64 sum order)", g->max_dv);
+    if (desc->c2v_form == LDPC_C2V_RCQ) {
+        if (desc->dtype != LDPC_F32) return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
+        if (desc->n_levels < 1 || desc->n_levels > 128) return fail(LDPC_ERR_UNSUPPORTED, "n_levels %d outside 1..128 (bc 1..8)", desc->n_levels);
+        if (desc->n_quantizers < 1 || !desc->thresholds || (desc->iters > 0 && !desc->q_of_iter)) return fail(LDPC_ERR_ARG, "quantiser tables missing");
+        for (int t = 0; t < desc->iters; ++t)
+            if (desc->q_of_iter[t] < 0 || desc->q_of_iter[t] >= desc->n_quantizers) return fail(LDPC_ERR_ARG, "q_of_iter[%d] out of range", t);
+    }
+    if (desc->c2v_form == LDPC_C2V_OMS && desc->oms_alpha) {
+        if (desc->n_oms_alpha_slots < 1 || (g->E > 0 && !desc->oms_alpha_slot)) return fail(LDPC_ERR_ARG, "oms_alpha tables missing");
+        for (int e = 0; e < g->E; ++e)
+            if (desc->oms_alpha_slot[e] < 0 || desc->oms_alpha_slot[e] >= desc->n_oms_alpha_slots) return fail(LDPC_ERR_ARG, "oms_alpha_slot[%d] out of range", e);
+    }
+
+    DeviceGuard guard(g->device);
+    ldpc_decoder *d = new (std::nothrow) ldpc_decoder();
+    if (!d) return fail(LDPC_ERR_ARG, "out of host memory");
+    d->g = g; d->dtype = desc->dtype; d->form = desc->c2v_form; d->T = desc->iters;
+    d->n_beta = desc->n_beta_slots; d->n_alpha = desc->n_alpha_slots;
+    const size_t es = d->elem();
+    const size_t rows = (size_t)std::max(d->T, 1);
+    int rc = LDPC_OK;
+    auto up_bytes = [&](void **dst, const void *src, size_t bytes) {
+        char *p = nullptr;
+        int r = upload(&p, (const char *)src, bytes);
+        *dst = p;
+        return r;
+    };
+    // tables have max(T,1) rows on the device; with T == 0 row 0 is never read for arithmetic
+    if (d->T > 0) {
+        rc = up_bytes(&d->beta, desc->beta, rows * d->n_beta * es);
+        if (!rc) rc = up_bytes(&d->alpha, desc->alpha, rows * d->n_alpha * es);
+    } else {
+        rc = up_bytes(&d->beta, nullptr, (size_t)d->n_beta * es);
+        if (!rc) rc = up_bytes(&d->alpha, nullptr, (size_t)d->n_alpha * es);
+    }
+    if (!rc) rc = upload(&d->beta_slot, desc->beta_slot, (size_t)g->E);
+    if (!rc) rc = upload(&d->alpha_slot, desc->alpha_slot, (size_t)g->n);
+    if (!rc && d->form == LDPC_C2V_RCQ) {
+        d->n_levels = desc->n_levels; d->n_quant = desc->n_quantizers;
+        d->q_of_iter.assign(desc->q_of_iter, desc->q_of_iter + d->T);
+        if (d->q_of_iter.empty()) d->q_of_iter.push_back(0);
+        const size_t L = d->n_levels, Q = d->n_quant;
+        rc = upload(&d->thresholds, desc->thresholds, Q * L);
+        // signed reconstruction LUT: value of code c = (1 - 2*sign_bit) * tau[c mod L]  (rcq_decoder.py:107-119)
+        std::vector<float> lut(Q * 2 * L);
+        for (size_t q = 0; q < Q; ++q)
+            for (size_t c = 0; c < 2 * L; ++c) {
+                const float sb = c >= L ? 1.0f : 0.0f;
+                lut[q * 2 * L + c] = (1.0f - 2.0f * sb) * desc->thresholds[q * L + (c % L)];
+            }
+        if (!rc) rc = upload(&d->lut, lut.data(), lut.size());
+    }
+    if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha && d->T > 0) {
+        d->n_oms_alpha = desc->n_oms_alpha_slots;
+        rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
+        if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
+    }
+    if (rc) {
+        ldpc_decoder_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_set_weights(ldpc_decoder *d, const void *beta, const void *alpha, const void *oms_alpha,
+                             void *stream)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
+    if (d->T == 0) return LDPC_OK;
+    DeviceGuard guard(d->g->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t es = d->elem(), rows = (size_t)d->T;
+    if (beta) HIP_TRY(hipMemcpyAsync(d->beta, beta, rows * d->n_beta * es, hipMemcpyHostToDevice, s));
+    if (alpha) HIP_TRY(hipMemcpyAsync(d->alpha, alpha, rows * d->n_alpha * es, hipMemcpyHostToDevice, s));
+    if (oms_alpha) {
+        if (!d->oms_alpha) return fail(LDPC_ERR_ARG, "decoder was created without oms_alpha");
+        HIP_TRY(hipMemcpyAsync(d->oms_alpha, oms_alpha, rows * d->n_oms_alpha * es, hipMemcpyHostToDevice, s));
+    }
+    return LDPC_OK;
+}
+
+void ldpc_decoder_destroy(ldpc_decoder *d)
+{
+    if (!d) return;
+    DeviceGuard guard(d->g->device);
+    (void)hipFree(d->beta); (void)hipFree(d->alpha); (void)hipFree(d->oms_alpha);
+    (void)hipFree(d->beta_slot); (void)hipFree(d->alpha_slot); (void)hipFree(d->oms_alpha_slot);
+    (void)hipFree(d->thresholds); (void)hipFree(d->lut);
+    delete d;
+}
+
+size_t ldpc_decoder_workspace_bytes(const ldpc_decoder *d, int64_t batch)
+{
+    if (!d || batch < 0) return 0;
+    return carve(d, batch, nullptr).total;
+}
+
+int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop, int32_t *bits,
+                void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed_bits,
+                void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
+    if (batch < 0) return fail(LDPC_ERR_ARG, "batch < 0");
+    if (batch == 0) return LDPC_OK;
+    if (!llr || !workspace) return fail(LDPC_ERR_ARG, "NULL llr/workspace");
+    if (d->g->n == 0) return LDPC_OK;
+    if (((uintptr_t)workspace % kAlign) != 0) return fail(LDPC_ERR_ARG, "workspace must be %zu-byte aligned", kAlign);
+    const Workspace w = carve(d, batch, workspace);
+    if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
+    if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
+    DeviceGuard guard(d->g->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == LDPC_F64)
+        return decode_dispatch<double>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
+    return decode_dispatch<float>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
+}
+
+int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])
+{
+    if (!d || !out8 || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
+    char *base = reinterpret_cast<char *>(kAlign);   // any non-null base: only differences are used
+    const Workspace w = carve(d, batch, base);
+    out8[0] = w.vec; out8[1] = w.tiles;
+    out8[2] = w.llrT - base; out8[3] = w.v2c - base; out8[4] = w.c2v - base; out8[5] = w.postT - base;
+    out8[6] = (char *)w.bitsT - base; out8[7] = (char *)w.done - base;
+    return LDPC_OK;
+}
+
+int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_t iter, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    if (!d || !workspace || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
+    if (iter < 0 || iter >= d->T) return fail(LDPC_ERR_ARG, "iter outside [0, T)");
+    const Workspace w = carve(d, batch, workspace);
+    if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace too small");
+    DeviceGuard guard(d->g->device);
+    hipStream_t s = (hipStream_t)stream;
+    const bool f64 = d->dtype == LDPC_F64;
+#define LDPC_DBG(REAL_, V_)                                                                 \
+    return which == 0 ? launch_cn<REAL_, V_>(d, w, iter, false, s)                           \
+                      : launch_vn<REAL_, V_>(d, w, iter, iter == d->T - 1, false, s)
+    if (f64) {
+        if (w.vec == 1) { LDPC_DBG(double, 1); } else { LDPC_DBG(double, 2); }
+    } else {
+        if (w.vec == 1) { LDPC_DBG(float, 1); } else { LDPC_DBG(float, 4); }
+    }
+#undef LDPC_DBG
+}
+
+}  // extern "C"

@@ -1,0 +1,675 @@
+// ldpc_kernels.hip -- gfx950 (MI355X) kernels of the batched flooding decoder.
+//
+// Mapping (DESIGN.md "Data layout"): a wavefront is 64 lanes x VEC consecutive
+// codewords sitting on ONE node of the Tanner graph.  Messages live in HBM as
+// [tile][edge][W] with W = 64*VEC codewords innermost, so every message access of a
+// wave is one contiguous W*sizeof(T) row (1 KiB for fp32/VEC=4) and every graph
+// index, weight and threshold is wave-uniform (scalar loads, SGPRs).  Both sweeps
+// are therefore coalesced; the CSC permutation of the variable sweep only selects
+// WHICH row.  No MFMA: there is no contraction here, the kernels are HBM streams.
+//
+// Arithmetic follows the reference exactly: unfused multiply/add
+// (-ffp-contract=off), torch.sum's fp32 association order / np.sum's fp64 order for
+// the variable sums, first-minimum arg-min, float32 thresholds.  The product of the
+// other edges' signs is kept as sign-bit parity (value-equivalent to the reference's
+// sign(0)=0 product for the NMS/RCQ rules; the OMS rule tracks zeros explicitly).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace ldpc {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;                 // 4 waves: 4 consecutive nodes of one tile
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+enum { FORM_NMS = 0, FORM_RCQ = 1, FORM_OMS = 2 };
+
+struct GraphDev {
+    int n, m, E;
+    const int *check_ptr;   // [m+1]
+    const int *var_idx;     // [E]  variable of CSR edge
+    const int *var_ptr;     // [n+1]
+    const int *csc_edge;    // [E]  CSR edge id of k-th edge of a variable
+};
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+    T x[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld(const T *p)
+{
+    return *reinterpret_cast<const Pack<T, V> *>(p);
+}
+template <typename T, int V>
+__device__ __forceinline__ void st(T *p, const Pack<T, V> &v)
+{
+    *reinterpret_cast<Pack<T, V> *>(p) = v;
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename T> struct Bits;
+template <> struct Bits<float> {
+    using U = uint32_t;
+    static __device__ __forceinline__ U get(float f) { return __float_as_uint(f); }
+    static __device__ __forceinline__ float put(U u) { return __uint_as_float(u); }
+    static constexpr int kSignShift = 31;
+};
+template <> struct Bits<double> {
+    using U = uint64_t;
+    static __device__ __forceinline__ U get(double f) { return (U)__double_as_longlong(f); }
+    static __device__ __forceinline__ double put(U u) { return __longlong_as_double((long long)u); }
+    static constexpr int kSignShift = 63;
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned signbit_of(T v)
+{
+    return (unsigned)(Bits<T>::get(v) >> Bits<T>::kSignShift);
+}
+template <typename T>
+__device__ __forceinline__ T flip_sign(T v, unsigned neg)
+{
+    using U = typename Bits<T>::U;
+    return Bits<T>::put(Bits<T>::get(v) ^ ((U)neg << Bits<T>::kSignShift));
+}
+template <typename T> __device__ __forceinline__ T abs_of(T v);
+template <> __device__ __forceinline__ float abs_of<float>(float v) { return __builtin_fabsf(v); }
+template <> __device__ __forceinline__ double abs_of<double>(double v) { return __builtin_fabs(v); }
+template <typename T> __device__ __forceinline__ T inf_of();
+template <> __device__ __forceinline__ float inf_of<float>() { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_of<double>() { return __builtin_huge_val(); }
+
+// per-lane "frozen" flags of the VEC codewords of this lane (early-stop latch)
+template <int VEC>
+struct Frozen {
+    unsigned bits;   // bit c = codeword c of this lane is done
+    __device__ __forceinline__ bool all() const { return bits == ((1u << VEC) - 1u); }
+    __device__ __forceinline__ bool none() const { return bits == 0; }
+    __device__ __forceinline__ bool one(int c) const { return (bits >> c) & 1u; }
+};
+
+// Returns true when every codeword of the wave is frozen (wave-uniform).
+template <int VEC>
+__device__ __forceinline__ bool load_frozen(const uint64_t *done, int tile, int lane, Frozen<VEC> &f)
+{
+    f.bits = 0;
+    if (!done) return false;
+    bool all = true;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        uint64_t w = done[(size_t)tile * VEC + c];
+        all = all && (w == ~0ull);
+        f.bits |= (unsigned)((w >> lane) & 1ull) << c;
+    }
+    return all;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_masked(T *p, const Pack<T, VEC> &v, const Frozen<VEC> &f)
+{
+    if (f.none()) {
+        st<T, VEC>(p, v);
+    } else if (!f.all()) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            if (!f.one(c)) p[c] = v.x[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Check-node (CN -> VN) sweep.  One wave = one check x W codewords.
+//   pass 1: stream the dc incoming rows, keep min1/min2/arg-min and the sign bits
+//   pass 2: emit dc outgoing rows  (fp rows, or 1-byte RCQ codes)
+// FIRST: iteration 0 reads llr[var] instead of v2c (the reference's "initialize with
+// channel LLRs", neural_2d_decoder.py:153-157, folded into the first sweep).
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int FORM, bool FIRST>
+__global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restrict__ src,
+                                                   void *__restrict__ c2v_out,
+                                                   const T *__restrict__ beta_row,
+                                                   const int *__restrict__ beta_slot,
+                                                   const float *__restrict__ thr, int n_levels,
+                                                   const T *__restrict__ oms_alpha_row,
+                                                   const int *__restrict__ oms_alpha_slot,
+                                                   const uint64_t *__restrict__ done, int check_blocks)
+{
+    constexpr int W = kWave * VEC;
+    using OutT = typename std::conditional<FORM == FORM_RCQ, uint8_t, T>::type;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / check_blocks);
+    const int i = uni((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
+    if (i >= g.m) return;
+    const int e0 = uni(g.check_ptr[i]);
+    const int dc = uni(g.check_ptr[i + 1]) - e0;
+    if (dc == 0) return;
+
+    Frozen<VEC> fz;
+    if (load_frozen<VEC>(done, tile, lane, fz)) return;
+
+    const size_t lane_off = (size_t)lane * VEC;
+    const T *in_base = FIRST ? src + (size_t)tile * g.n * W + lane_off
+                             : src + ((size_t)tile * g.E + e0) * W + lane_off;
+
+    T m1[VEC], m2[VEC];
+    int idx[VEC];
+    uint32_t sm[VEC], zm[VEC];
+    unsigned par[VEC], nz[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        m1[c] = inf_of<T>(); m2[c] = inf_of<T>(); idx[c] = 0; sm[c] = 0; zm[c] = 0; par[c] = 0; nz[c] = 0;
+    }
+
+#pragma unroll 4
+    for (int t = 0; t < dc; ++t) {
+        const T *row = FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W;
+        Pack<T, VEC> v = ld<T, VEC>(row);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            T a = abs_of<T>(v.x[c]);
+            unsigned sb = signbit_of<T>(v.x[c]);
+            par[c] ^= sb;
+            sm[c] |= sb << (t & 31);
+            if (FORM == FORM_OMS) {
+                unsigned z = (a == (T)0) ? 1u : 0u;
+                nz[c] += z;
+                zm[c] |= z << (t & 31);
+            }
+            if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; idx[c] = t; }
+            else if (a < m2[c]) { m2[c] = a; }
+        }
+    }
+    if (dc == 1) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) m2[c] = m1[c];   // "min2_val = min_val" (neural_2d_decoder.py:181-182)
+    }
+
+    const bool wide = dc > 32;   // sign masks hold 32 edges; wider checks re-read their inputs
+    // quantiser thresholds: up to 8 levels (bc <= 4) live in SGPRs; NaN padding never matches
+    float th[8];
+    if (FORM == FORM_RCQ) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
+    }
+    OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
+
+#pragma unroll 4
+    for (int t = 0; t < dc; ++t) {
+        const T b = beta_row[beta_slot[e0 + t]];
+        T oa = (T)0;
+        if (FORM == FORM_OMS && oms_alpha_row) oa = oms_alpha_row[oms_alpha_slot[e0 + t]];
+        Pack<T, VEC> re;
+        if (wide) {
+            const T *row = FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W;
+            re = ld<T, VEC>(row);
+        }
+        Pack<OutT, VEC> o;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const T raw = (t == idx[c]) ? m2[c] : m1[c];
+            unsigned own = wide ? signbit_of<T>(re.x[c]) : ((sm[c] >> (t & 31)) & 1u);
+            unsigned neg = par[c] ^ own;
+            if (FORM == FORM_NMS) {
+                o.x[c] = (OutT)flip_sign<T>(b * raw, neg);
+            } else if (FORM == FORM_OMS) {
+                unsigned ownz = wide ? ((re.x[c] == (T)0) ? 1u : 0u) : ((zm[c] >> (t & 31)) & 1u);
+                bool nonzero = (nz[c] - ownz) == 0;         // no OTHER edge carries a zero
+                T d = raw - b;
+                T r = d > (T)0 ? d : (T)0;
+                T val = r - oa;
+                o.x[c] = (OutT)(nonzero ? flip_sign<T>(val, neg) : (T)0);
+            } else {
+                float w = flip_sign<float>((float)(b * raw), neg);
+                float mag = __builtin_fabsf(w);
+                int lvl = 0;                                                          // rcq_decoder.py:79-85
+                if (n_levels <= 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;
+                } else {
+                    for (int q = 0; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
+                }
+                int code = ((w < 0.0f) ? n_levels : 0) + lvl;                         // :88-89
+                o.x[c] = (OutT)code;
+            }
+        }
+        store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Compile-time sums in the reference's association order.
+//   ORDER 0: torch.sum fp32 (ATen row_sum, ILP 4; N == 8 takes the 8-lane vector path)
+//   ORDER 1: np.sum fp64 pairwise (sequential below 8, 8 accumulators at 8)
+// x has DV elements; element u of the summed list is x[u] with index SKIP removed.
+// ------------------------------------------------------------------------------------------
+template <int N, int SKIP, int ORDER, typename T, int DV>
+__device__ __forceinline__ T sum_ct(const T (&x)[DV])
+{
+#define LDPC_AT(u) x[((SKIP) >= 0 && (u) >= (SKIP)) ? (u) + 1 : (u)]
+    if constexpr (N == 0) {
+        return (T)0;
+    } else if constexpr (ORDER == 0) {
+        if constexpr (N < 8) {
+            T p[4] = {(T)0, (T)0, (T)0, (T)0};
+            constexpr int G = N / 4;
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k] = p[k] + LDPC_AT(4 * r + k);
+            }
+#pragma unroll
+            for (int u = 4 * G; u < N; ++u) p[0] = p[0] + LDPC_AT(u);
+            p[0] = p[0] + p[1];
+            p[0] = p[0] + p[2];
+            p[0] = p[0] + p[3];
+            return p[0];
+        } else {
+            static_assert(N == 8, "compile-time torch order only up to 8 operands");
+            T fin = (T)0;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                T q = (T)0 + LDPC_AT(l);
+                q = q + (T)0; q = q + (T)0; q = q + (T)0;
+                fin = fin + q;
+            }
+            return fin;
+        }
+    } else {
+        if constexpr (N < 8) {
+            T res = (T)-0.0;
+#pragma unroll
+            for (int u = 0; u < N; ++u) res = res + LDPC_AT(u);
+            return res;
+        } else {
+            static_assert(N == 8, "compile-time numpy order only up to 8 operands");
+            return ((LDPC_AT(0) + LDPC_AT(1)) + (LDPC_AT(2) + LDPC_AT(3))) +
+                   ((LDPC_AT(4) + LDPC_AT(5)) + (LDPC_AT(6) + LDPC_AT(7)));
+        }
+    }
+#undef LDPC_AT
+}
+
+// Run-time sums for variables of degree > 8: operands are re-fetched through `get`
+// (L1/L2 hits), VEC codewords at a time.  Same association orders, any N the host
+// admits (torch order N <= 575, numpy order N <= 128).
+template <int ORDER, typename T, int VEC, typename Get>
+__device__ __forceinline__ Pack<T, VEC> sum_rt(int N, Get get)
+{
+    Pack<T, VEC> fin;
+    auto add = [](Pack<T, VEC> &a, const Pack<T, VEC> &b) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) a.x[c] = a.x[c] + b.x[c];
+    };
+    auto zero = [](Pack<T, VEC> &a, T v) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) a.x[c] = v;
+    };
+    if (ORDER == 0) {
+        if (N < 8) {
+            Pack<T, VEC> p[4];
+            for (int k = 0; k < 4; ++k) zero(p[k], (T)0);
+            const int G = N / 4;
+            for (int r = 0; r < G; ++r)
+                for (int k = 0; k < 4; ++k) add(p[k], get(4 * r + k));
+            for (int u = 4 * G; u < N; ++u) add(p[0], get(u));
+            add(p[0], p[1]); add(p[0], p[2]); add(p[0], p[3]);
+            return p[0];
+        }
+        const int V = N / 8, G = V / 4;
+        zero(fin, (T)0);
+        for (int u = 8 * V; u < N; ++u) add(fin, get(u));
+        for (int l = 0; l < 8; ++l) {
+            Pack<T, VEC> p0, p1, p2, p3;
+            zero(p0, (T)0); zero(p1, (T)0); zero(p2, (T)0); zero(p3, (T)0);
+            for (int r = 0; r < G; ++r) {
+                add(p0, get((4 * r + 0) * 8 + l));
+                add(p1, get((4 * r + 1) * 8 + l));
+                add(p2, get((4 * r + 2) * 8 + l));
+                add(p3, get((4 * r + 3) * 8 + l));
+            }
+            for (int v = 4 * G; v < V; ++v) add(p0, get(v * 8 + l));
+            add(p0, p1); add(p0, p2); add(p0, p3);
+            add(fin, p0);
+        }
+        return fin;
+    } else {
+        if (N == 0) { zero(fin, (T)0); return fin; }
+        if (N < 8) {
+            zero(fin, (T)-0.0);
+            for (int u = 0; u < N; ++u) add(fin, get(u));
+            return fin;
+        }
+        // 8 <= N <= 128 (host rejects larger degrees for this order)
+        Pack<T, VEC> r0 = get(0), r1 = get(1), r2 = get(2), r3 = get(3), r4 = get(4), r5 = get(5), r6 = get(6), r7 = get(7);
+        int u = 8;
+        for (; u < N - (N % 8); u += 8) {
+            add(r0, get(u)); add(r1, get(u + 1)); add(r2, get(u + 2)); add(r3, get(u + 3));
+            add(r4, get(u + 4)); add(r5, get(u + 5)); add(r6, get(u + 6)); add(r7, get(u + 7));
+        }
+        add(r0, r1); add(r2, r3); add(r4, r5); add(r6, r7);
+        add(r0, r2); add(r4, r6);
+        add(r0, r4);
+        for (; u < N; ++u) add(r0, get(u));
+        return r0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Variable-node sweep.  One wave = one variable x W codewords: gathers the dv C2V rows
+// (CSC order), forms the dv leave-one-out sums and the posterior in the reference's
+// association order, writes dv V2C rows, the hard-decision ballots and (LAST) the posterior.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, bool CODES>
+__device__ __forceinline__ Pack<T, VEC> load_c2v(const void *c2v, size_t elem_off, const float *lut)
+{
+    if constexpr (CODES) {
+        Pack<uint8_t, VEC> q = ld<uint8_t, VEC>(reinterpret_cast<const uint8_t *>(c2v) + elem_off);
+        Pack<T, VEC> r;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) r.x[c] = (T)lut[q.x[c]];   // reconstruction LUT in LDS
+        return r;
+    } else {
+        return ld<T, VEC>(reinterpret_cast<const T *>(c2v) + elem_off);
+    }
+}
+
+template <typename T, int VEC, bool CODES, int ORDER, bool LAST, int DV>
+__device__ __forceinline__ void vn_body(const GraphDev &g, int tile, int j, int s0, int lane,
+                                        const void *__restrict__ c2v, const T *__restrict__ llrT,
+                                        T *__restrict__ v2c, T a, const float *lut,
+                                        uint64_t *__restrict__ bitsT, T *__restrict__ postT,
+                                        const Frozen<VEC> &fz)
+{
+    constexpr int W = kWave * VEC;
+    const size_t lane_off = (size_t)lane * VEC;
+    const size_t tileE = (size_t)tile * g.E;
+    int e[DV > 0 ? DV : 1];
+    Pack<T, VEC> x[DV > 0 ? DV : 1];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) x[k] = load_c2v<T, VEC, CODES>(c2v, (tileE + e[k]) * W + lane_off, lut);
+    const Pack<T, VEC> l = ld<T, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+
+    Pack<T, VEC> post;
+    Pack<T, VEC> out[DV > 0 ? DV : 1];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        T xs[DV > 0 ? DV : 1];
+#pragma unroll
+        for (int k = 0; k < DV; ++k) xs[k] = x[k].x[c];
+        post.x[c] = l.x[c] + sum_ct<DV, -1, ORDER, T>(xs);           // posterior: no alpha (:206-209)
+        if constexpr (!LAST) {
+            // v2c = llr + alpha * sum(others)  (neural_2d_decoder.py:200-203)
+            if constexpr (DV >= 1) out[0].x[c] = l.x[c] + a * sum_ct<DV - 1, 0, ORDER, T>(xs);
+            if constexpr (DV >= 2) out[1].x[c] = l.x[c] + a * sum_ct<DV - 1, 1, ORDER, T>(xs);
+            if constexpr (DV >= 3) out[2].x[c] = l.x[c] + a * sum_ct<DV - 1, 2, ORDER, T>(xs);
+            if constexpr (DV >= 4) out[3].x[c] = l.x[c] + a * sum_ct<DV - 1, 3, ORDER, T>(xs);
+            if constexpr (DV >= 5) out[4].x[c] = l.x[c] + a * sum_ct<DV - 1, 4, ORDER, T>(xs);
+            if constexpr (DV >= 6) out[5].x[c] = l.x[c] + a * sum_ct<DV - 1, 5, ORDER, T>(xs);
+            if constexpr (DV >= 7) out[6].x[c] = l.x[c] + a * sum_ct<DV - 1, 6, ORDER, T>(xs);
+            if constexpr (DV >= 8) out[7].x[c] = l.x[c] + a * sum_ct<DV - 1, 7, ORDER, T>(xs);
+        }
+    }
+    if constexpr (!LAST) {
+#pragma unroll
+        for (int k = 0; k < DV; ++k) store_masked<T, VEC>(v2c + (tileE + e[k]) * W + lane_off, out[k], fz);
+    }
+    // hard decision: one 64-bit ballot per codeword position c  (posterior < 0)
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        uint64_t mask = __ballot(post.x[c] < (T)0);
+        if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
+    }
+    if constexpr (LAST) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);
+}
+
+template <typename T, int VEC, bool CODES, int ORDER, bool LAST>
+__device__ __noinline__ void vn_generic(const GraphDev &g, int tile, int j, int s0, int dv, int lane,
+                                        const void *__restrict__ c2v, const T *__restrict__ llrT,
+                                        T *__restrict__ v2c, T a, const float *lut,
+                                        uint64_t *__restrict__ bitsT, T *__restrict__ postT,
+                                        const Frozen<VEC> &fz)
+{
+    constexpr int W = kWave * VEC;
+    const size_t lane_off = (size_t)lane * VEC;
+    const size_t tileE = (size_t)tile * g.E;
+    const Pack<T, VEC> l = ld<T, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+    auto fetch = [&](int k) {
+        return load_c2v<T, VEC, CODES>(c2v, (tileE + g.csc_edge[s0 + k]) * W + lane_off, lut);
+    };
+    Pack<T, VEC> post = sum_rt<ORDER, T, VEC>(dv, fetch);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) post.x[c] = l.x[c] + post.x[c];
+    if (!LAST) {
+        for (int k = 0; k < dv; ++k) {
+            auto others = [&](int u) { return fetch(u < k ? u : u + 1); };
+            Pack<T, VEC> s = sum_rt<ORDER, T, VEC>(dv - 1, others);
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) o.x[c] = l.x[c] + a * s.x[c];
+            store_masked<T, VEC>(v2c + (tileE + g.csc_edge[s0 + k]) * W + lane_off, o, fz);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        uint64_t mask = __ballot(post.x[c] < (T)0);
+        if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
+    }
+    if (LAST) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);
+}
+
+template <typename T, int VEC, bool CODES, bool LAST>
+__global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__restrict__ c2v,
+                                                   const T *__restrict__ llrT, T *__restrict__ v2c,
+                                                   const T *__restrict__ alpha_row,
+                                                   const int *__restrict__ alpha_slot,
+                                                   const float *__restrict__ lut_global, int lut_size,
+                                                   uint64_t *__restrict__ bitsT, T *__restrict__ postT,
+                                                   const uint64_t *__restrict__ done, int var_blocks)
+{
+    constexpr int ORDER = sizeof(T) == 8 ? 1 : 0;   // fp64 = numpy decoder, fp32 = torch decoders
+    __shared__ float lut[256];
+    if (CODES) {
+        if ((int)threadIdx.x < lut_size) lut[threadIdx.x] = lut_global[threadIdx.x];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int j = uni((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
+    if (j >= g.n) return;
+    const int s0 = uni(g.var_ptr[j]);
+    const int dv = uni(g.var_ptr[j + 1]) - s0;
+
+    Frozen<VEC> fz;
+    const bool all_frozen = load_frozen<VEC>(done, tile, lane, fz);
+    if (!LAST && all_frozen) return;    // LAST still has to publish the latched posterior
+    const T a = alpha_row[alpha_slot[j]];
+
+#define LDPC_VN_CASE(D) \
+    case D: vn_body<T, VEC, CODES, ORDER, LAST, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut, bitsT, postT, fz); break;
+    switch (dv) {
+        LDPC_VN_CASE(0) LDPC_VN_CASE(1) LDPC_VN_CASE(2) LDPC_VN_CASE(3) LDPC_VN_CASE(4)
+        LDPC_VN_CASE(5) LDPC_VN_CASE(6) LDPC_VN_CASE(7) LDPC_VN_CASE(8)
+    default:
+        vn_generic<T, VEC, CODES, ORDER, LAST>(g, tile, j, s0, dv, lane, c2v, llrT, v2c, a, lut, bitsT, postT, fz);
+    }
+#undef LDPC_VN_CASE
+}
+
+// ------------------------------------------------------------------------------------------
+// Syndrome + early-stop latch.  One block per tile; H @ bits mod 2 becomes an XOR of
+// the ballot words of a check's variables (64 codewords per word).
+//   latch = true : done |= (syndrome == 0); iterations = it+1 for newly done codewords
+//   latch = false: fixed-T mode, done := (syndrome == 0)   (reported as `success`)
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint64_t *__restrict__ bitsT,
+                                                         uint64_t *__restrict__ done,
+                                                         int *__restrict__ iters, int it_plus_1, int latch)
+{
+    constexpr int W = kWave * VEC;
+    __shared__ unsigned long long unsat[VEC];
+    const int tile = blockIdx.x;
+    if (threadIdx.x < VEC) unsat[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (latch) {
+        bool all = true;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) all = all && (done[(size_t)tile * VEC + c] == ~0ull);
+        if (all) return;
+    }
+    uint64_t acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0;
+    const uint64_t *b = bitsT + (size_t)tile * g.n * VEC;
+    for (int i = threadIdx.x; i < g.m; i += kBlock) {
+        uint64_t x[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c] = 0;
+        const int e1 = g.check_ptr[i + 1];
+        for (int e = g.check_ptr[i]; e < e1; ++e) {
+            const uint64_t *w = b + (size_t)g.var_idx[e] * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) x[c] ^= w[c];
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] |= x[c];
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c)
+        if (acc[c]) atomicOr(&unsat[c], (unsigned long long)acc[c]);
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
+        const int w = threadIdx.x, c = w % VEC, l = w / VEC;
+        const uint64_t sat = ~(uint64_t)unsat[c];
+        if (latch) {
+            const uint64_t was = done[(size_t)tile * VEC + c];
+            if (((sat & ~was) >> l) & 1ull) iters[(size_t)tile * W + w] = it_plus_1;
+        }
+    }
+    __syncthreads();   // all reads of `done` above precede the update below
+    if ((int)threadIdx.x < VEC) {
+        const int c = threadIdx.x;
+        const uint64_t sat = ~(uint64_t)unsat[c];
+        done[(size_t)tile * VEC + c] = latch ? (done[(size_t)tile * VEC + c] | sat) : sat;
+    }
+}
+
+// done masks: padding codewords (>= batch) start frozen; iterations start at T
+template <int VEC>
+__global__ void init_state(uint64_t *__restrict__ done, int *__restrict__ iters, long long batch,
+                           int tiles, int T)
+{
+    constexpr int W = kWave * VEC;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < (long long)tiles * W) iters[gid] = T;
+    if (gid < (long long)tiles * VEC) {
+        const int tile = (int)(gid / VEC), c = (int)(gid % VEC);
+        uint64_t mask = 0;
+        for (int l = 0; l < kWave; ++l) {
+            long long b = (long long)tile * W + (long long)l * VEC + c;
+            if (b >= batch) mask |= 1ull << l;
+        }
+        done[gid] = mask;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout changes at the API edge: llr[B][n] -> llrT[tile][n][W]; posterior / bits back.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void transpose_in(const T *__restrict__ llr, T *__restrict__ llrT,
+                                                       long long batch, int n, int var_chunks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int JT = 128 / sizeof(T);
+    __shared__ T s[JT][W + 1];
+    const int tile = blockIdx.x / var_chunks;
+    const int j0 = (blockIdx.x % var_chunks) * JT;
+    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+        const int r = idx / JT, jj = idx % JT;
+        const long long b = (long long)tile * W + r;
+        T v = (T)1;                                     // padding codewords: benign positive LLR
+        if (b < batch && j0 + jj < n) v = llr[(size_t)b * n + j0 + jj];
+        s[jj][r] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+        const int jj = idx / W, w = idx % W;
+        if (j0 + jj < n) llrT[((size_t)tile * n + j0 + jj) * W + w] = s[jj][w];
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void transpose_out(const T *__restrict__ postT,
+                                                        const uint64_t *__restrict__ bitsT,
+                                                        T *__restrict__ posterior, int *__restrict__ bits,
+                                                        long long batch, int n, int var_chunks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int JT = 128 / sizeof(T);
+    __shared__ T s[JT][W + 1];
+    __shared__ uint64_t sb[JT][VEC];
+    const int tile = blockIdx.x / var_chunks;
+    const int j0 = (blockIdx.x % var_chunks) * JT;
+    if (posterior) {
+        for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+            const int jj = idx / W, w = idx % W;
+            if (j0 + jj < n) s[jj][w] = postT[((size_t)tile * n + j0 + jj) * W + w];
+        }
+    }
+    if (bits) {
+        for (int idx = threadIdx.x; idx < JT * VEC; idx += kBlock) {
+            const int jj = idx / VEC, c = idx % VEC;
+            sb[jj][c] = (j0 + jj < n) ? bitsT[((size_t)tile * n + j0 + jj) * VEC + c] : 0ull;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+        const int r = idx / JT, jj = idx % JT;
+        const long long b = (long long)tile * W + r;
+        if (b < batch && j0 + jj < n) {
+            if (posterior) posterior[(size_t)b * n + j0 + jj] = s[jj][r];
+            if (bits) bits[(size_t)b * n + j0 + jj] = (int)((sb[jj][r % VEC] >> (r / VEC)) & 1ull);
+        }
+    }
+}
+
+// iterations / success / packed hard decisions, one thread per (codeword, output byte)
+template <int VEC>
+__global__ void finalize_out(const uint64_t *__restrict__ done, const int *__restrict__ iters_ws,
+                             const uint64_t *__restrict__ bitsT, int *__restrict__ iterations,
+                             uint8_t *__restrict__ success, uint8_t *__restrict__ packed,
+                             long long batch, int n)
+{
+    constexpr int W = kWave * VEC;
+    const int nbytes = (n + 7) / 8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < batch) {
+        const int tile = (int)(gid / W), w = (int)(gid % W);
+        if (iterations) iterations[gid] = iters_ws[gid];
+        if (success) success[gid] = (uint8_t)((done[(size_t)tile * VEC + (w % VEC)] >> (w / VEC)) & 1ull);
+    }
+    if (packed) {
+        const long long total = batch * nbytes;
+        for (long long k = gid; k < total; k += (long long)gridDim.x * blockDim.x) {
+            const long long b = k / nbytes;
+            const int byte = (int)(k % nbytes);
+            const int tile = (int)(b / W), w = (int)(b % W);
+            unsigned v = 0;
+            for (int q = 0; q < 8; ++q) {
+                const int j = byte * 8 + q;
+                if (j < n) v |= (unsigned)((bitsT[((size_t)tile * n + j) * VEC + (w % VEC)] >> (w / VEC)) & 1ull) << q;
+            }
+            packed[k] = (uint8_t)v;
+        }
+    }
+}
+
+}  // namespace ldpc

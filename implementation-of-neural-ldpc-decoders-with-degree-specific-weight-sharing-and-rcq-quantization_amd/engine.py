@@ -1,0 +1,224 @@
+"""
+Batched decode engine: Python owner of the native handles (include/ldpc_hip.h).
+
+One ``DecodeEngine`` = one Tanner graph + one decoder descriptor (C2V rule,
+weight tables, quantiser tables) on one GPU.  PyTorch is used only as plumbing:
+device memory (``torch.empty``), the current HIP stream, and dtype bookkeeping.
+The arithmetic runs in the hand-written HIP kernels; there is no CPU path.
+
+The host decoder classes (ldpc_decoder.py, neural_2d_decoder.py, rcq_decoder.py)
+flatten their reference-style parameters into the tables this class uploads.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+import _native as nat
+from tanner_graph import TannerGraph
+
+
+@dataclass
+class DecodeResult:
+    """Row-wise map of the reference's return tuple over a batch."""
+    bits: Optional[torch.Tensor]          # int32 [B, n]     (posterior < 0)
+    posterior: Optional[torch.Tensor]     # dtype [B, n]
+    iterations: torch.Tensor              # int32 [B]        1-based, T when not converged
+    success: torch.Tensor                 # bool  [B]
+    packed_bits: Optional[torch.Tensor] = None   # uint8 [B, ceil(n/8)]
+
+
+def _require_gpu(device) -> torch.device:
+    if not torch.cuda.is_available():
+        raise nat.NativeEngineError(
+            "no HIP device visible: the LDPC decode path runs only on the MI355X engine "
+            "(libldpc_hip.so); there is no CPU fallback")
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise nat.NativeEngineError(f"decode device must be a ROCm GPU, got {dev}")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class _NativeGraph:
+    """ldpc_graph* for (graph, device); shared by all engines on that graph."""
+    _cache = {}
+    _lock = threading.Lock()
+
+    def __init__(self, graph: TannerGraph, device: torch.device):
+        lib = nat.load()
+        self.handle = C.c_void_p()
+        with torch.cuda.device(device):
+            cp = np.ascontiguousarray(graph.check_ptr, dtype=np.int32)
+            vi = np.ascontiguousarray(graph.var_idx, dtype=np.int32)
+            nat.check(lib.ldpc_graph_create(C.byref(self.handle), graph.n, graph.m, graph.E,
+                                            nat.ptr(cp), nat.ptr(vi)), "ldpc_graph_create")
+        self._lib = lib
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                self._lib.ldpc_graph_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    @classmethod
+    def get(cls, graph: TannerGraph, device: torch.device) -> "_NativeGraph":
+        key = (id(graph), device.index)
+        with cls._lock:
+            hit = cls._cache.get(key)
+            if hit is not None and hit[0] is graph:
+                return hit[1]
+            ng = cls(graph, device)
+            cls._cache[key] = (graph, ng)
+            return ng
+
+
+class DecodeEngine:
+    def __init__(self, graph: TannerGraph, *, dtype: torch.dtype, c2v_form: int, iters: int,
+                 beta: np.ndarray, beta_slot: np.ndarray, alpha: np.ndarray, alpha_slot: np.ndarray,
+                 thresholds: Optional[np.ndarray] = None, q_of_iter: Optional[np.ndarray] = None,
+                 oms_alpha: Optional[np.ndarray] = None, oms_alpha_slot: Optional[np.ndarray] = None,
+                 device=None):
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError("engine dtype must be float32 or float64")
+        self.device = _require_gpu(device)
+        self.graph = graph
+        self.dtype = dtype
+        self.np_dtype = np.float32 if dtype == torch.float32 else np.float64
+        self.iters = int(iters)
+        self.c2v_form = int(c2v_form)
+        lib = nat.load()
+        self._lib = lib
+        self._ng = _NativeGraph.get(graph, self.device)
+        rows = max(self.iters, 1)
+        beta = np.ascontiguousarray(beta, dtype=self.np_dtype).reshape(rows, -1)
+        alpha = np.ascontiguousarray(alpha, dtype=self.np_dtype).reshape(rows, -1)
+        beta_slot = np.ascontiguousarray(beta_slot, dtype=np.int32)
+        alpha_slot = np.ascontiguousarray(alpha_slot, dtype=np.int32)
+        if beta_slot.shape != (graph.E,) or alpha_slot.shape != (graph.n,):
+            raise ValueError("slot arrays must have one entry per edge / per variable")
+        desc = nat.DecoderDesc()
+        desc.dtype = nat.LDPC_F32 if dtype == torch.float32 else nat.LDPC_F64
+        desc.c2v_form, desc.iters = self.c2v_form, self.iters
+        desc.n_beta_slots, desc.beta, desc.beta_slot = beta.shape[1], nat.ptr(beta), nat.ptr(beta_slot)
+        desc.n_alpha_slots, desc.alpha, desc.alpha_slot = alpha.shape[1], nat.ptr(alpha), nat.ptr(alpha_slot)
+        keep = [beta, alpha, beta_slot, alpha_slot]
+        if self.c2v_form == nat.C2V_RCQ:
+            thresholds = np.ascontiguousarray(thresholds, dtype=np.float32)
+            q_of_iter = np.ascontiguousarray(q_of_iter, dtype=np.int32)
+            if thresholds.ndim != 2 or q_of_iter.shape[0] < self.iters:
+                raise ValueError("bad quantiser tables")
+            desc.n_quantizers, desc.n_levels = thresholds.shape
+            desc.thresholds, desc.q_of_iter = nat.ptr(thresholds), nat.ptr(q_of_iter)
+            keep += [thresholds, q_of_iter]
+        if self.c2v_form == nat.C2V_OMS and oms_alpha is not None:
+            oms_alpha = np.ascontiguousarray(oms_alpha, dtype=self.np_dtype).reshape(rows, -1)
+            oms_alpha_slot = np.ascontiguousarray(oms_alpha_slot, dtype=np.int32)
+            desc.n_oms_alpha_slots = oms_alpha.shape[1]
+            desc.oms_alpha, desc.oms_alpha_slot = nat.ptr(oms_alpha), nat.ptr(oms_alpha_slot)
+            keep += [oms_alpha, oms_alpha_slot]
+        self._table_shapes = (beta.shape, alpha.shape, None if oms_alpha is None else oms_alpha.shape)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(lib.ldpc_decoder_create(C.byref(self.handle), self._ng.handle, C.byref(desc)),
+                      "ldpc_decoder_create")
+        self._ws: Optional[torch.Tensor] = None
+        self._pending_host = None   # host arrays of an in-flight async weight upload
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                self._lib.ldpc_decoder_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, beta: Optional[np.ndarray], alpha: Optional[np.ndarray],
+                    oms_alpha: Optional[np.ndarray] = None):
+        """Re-upload weight tables (same shapes) -- e.g. after loading a state_dict."""
+        if beta is not None:
+            beta = np.ascontiguousarray(beta, dtype=self.np_dtype).reshape(self._table_shapes[0])
+        if alpha is not None:
+            alpha = np.ascontiguousarray(alpha, dtype=self.np_dtype).reshape(self._table_shapes[1])
+        if oms_alpha is not None:
+            oms_alpha = np.ascontiguousarray(oms_alpha, dtype=self.np_dtype).reshape(self._table_shapes[2])
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            nat.check(self._lib.ldpc_decoder_set_weights(self.handle, nat.ptr(beta), nat.ptr(alpha),
+                                                         nat.ptr(oms_alpha), C.c_void_p(stream.cuda_stream)),
+                      "ldpc_decoder_set_weights")
+            stream.synchronize()     # pageable host arrays: make the upload complete before they die
+
+    # ------------------------------------------------------------------ decode
+    def workspace_bytes(self, batch: int) -> int:
+        return int(self._lib.ldpc_decoder_workspace_bytes(self.handle, int(batch)))
+
+    def _workspace(self, batch: int) -> torch.Tensor:
+        need = self.workspace_bytes(batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def decode(self, llr: torch.Tensor, *, early_stop: bool = True, want_bits: bool = True,
+               want_posterior: bool = True, want_packed: bool = False) -> DecodeResult:
+        """llr: [B, n] tensor on this engine's GPU, dtype == engine dtype."""
+        if llr.device != self.device:
+            raise ValueError(f"llr is on {llr.device}, engine on {self.device}")
+        if llr.dtype != self.dtype:
+            raise TypeError(f"llr dtype {llr.dtype} != engine dtype {self.dtype}")
+        if llr.dim() != 2 or llr.shape[1] != self.graph.n:
+            raise ValueError(f"llr must have shape [B, {self.graph.n}], got {tuple(llr.shape)}")
+        llr = llr.contiguous()
+        B, n = llr.shape
+        dev = self.device
+        bits = torch.empty((B, n), dtype=torch.int32, device=dev) if want_bits else None
+        post = torch.empty((B, n), dtype=self.dtype, device=dev) if want_posterior else None
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        succ = torch.empty((B,), dtype=torch.uint8, device=dev)
+        packed = torch.empty((B, (n + 7) // 8), dtype=torch.uint8, device=dev) if want_packed else None
+        if B > 0:
+            ws = self._workspace(B)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+                nat.check(self._lib.ldpc_decode(self.handle, p(llr), B, int(bool(early_stop)), p(bits), p(post),
+                                                p(iters), p(succ), p(packed), p(ws), ws.numel(),
+                                                C.c_void_p(stream)), "ldpc_decode")
+        return DecodeResult(bits, post, iters, succ.bool(), packed)
+
+    def debug_sweep(self, batch: int, which: int, it: int):
+        """Launch one CN (which=0) or VN (which=1) sweep on the state a previous
+        decode(batch) left in the workspace -- bench.py's per-kernel timing hook."""
+        ws = self._workspace(batch)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            nat.check(self._lib.ldpc_debug_sweep(self.handle, int(batch), int(which), int(it),
+                                                 C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)),
+                      "ldpc_debug_sweep")
+
+    def debug_c2v(self, batch: int) -> torch.Tensor:
+        """C2V state left by the last decode(batch): [B, E] uint8 quantiser codes (RCQ) or
+        dtype values, CSR edge order.  Test hook (per-edge code parity with the reference)."""
+        out8 = np.zeros(8, dtype=np.int64)
+        nat.check(self._lib.ldpc_debug_workspace_layout(self.handle, int(batch), nat.ptr(out8)),
+                  "ldpc_debug_workspace_layout")
+        vec, tiles, off = int(out8[0]), int(out8[1]), int(out8[4])
+        W, E = 64 * vec, self.graph.E
+        ws = self._workspace(batch)
+        if self.c2v_form == nat.C2V_RCQ:
+            raw = ws[off: off + tiles * E * W].view(tiles, E, W)
+        else:
+            es = 4 if self.dtype == torch.float32 else 8
+            raw = ws[off: off + tiles * E * W * es].view(self.dtype).view(tiles, E, W)
+        return raw.permute(0, 2, 1).reshape(tiles * W, E)[:batch].contiguous()

@@ -1,0 +1,138 @@
+/*
+ * ldpc_hip.h -- C ABI of the MI355X (gfx950) batched LDPC decode engine.
+ *
+ * The reference (Lalwaniamisha789/Implementation-of-Neural-LDPC-Decoders-...)
+ * has no FFI or operator registry: its boundary is the Python class surface
+ *     BasicMinSumDecoder.decode            ldpc_decoder.py:63-153
+ *     Neural2DMinSumDecoder.forward        neural_2d_decoder.py:133-225
+ *     Neural2DOffsetMinSumDecoder.forward  neural_2d_decoder.py:338-434
+ *     RCQMinSumDecoder.decode              rcq_decoder.py:169-279
+ *     WeightedRCQDecoder.forward           rcq_decoder.py:495-597
+ * Every one of those is the same flooding loop with a different C2V rule and
+ * weight lookup, so the native boundary is ONE decode entry point driven by a
+ * descriptor; the Python classes of the same names (package directory) are thin
+ * hosts over it.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C types only; "device" pointers are HIP device pointers on the
+ *     device that was current when the graph was created;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it, nothing synchronises, nothing allocates: the
+ *     caller provides the workspace (ldpc_decoder_workspace_bytes);
+ *   - handles are immutable after creation and may be shared by threads; one
+ *     workspace per concurrent ldpc_decode call;
+ *   - every function returns LDPC_OK (0) or a negative LDPC_ERR_*;
+ *     ldpc_last_error() gives a thread-local message.
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDPC_HIP_ABI_VERSION 1
+
+enum {
+    LDPC_OK = 0,
+    LDPC_ERR_ARG = -1,          /* bad argument / inconsistent descriptor        */
+    LDPC_ERR_HIP = -2,          /* a HIP runtime call failed                     */
+    LDPC_ERR_UNSUPPORTED = -3,  /* valid request the engine does not implement   */
+    LDPC_ERR_WORKSPACE = -4     /* workspace too small                           */
+};
+
+/* arithmetic type of messages, weights, LLRs and posteriors */
+enum { LDPC_F32 = 0, LDPC_F64 = 1 };
+
+/* check-to-variable rule; `min` is min1 (min2 on the arg-min edge), `s` the
+ * product of the other edges' signs with sign(0) = 0 */
+enum {
+    LDPC_C2V_NMS = 0,  /* c2v = (beta * min) * s             ldpc_decoder.py:118-120, neural_2d_decoder.py:189-191 */
+    LDPC_C2V_RCQ = 1,  /* c2v = deq(quant((beta * s) * min)) rcq_decoder.py:242-246, 559-563 (1-byte codes in HBM) */
+    LDPC_C2V_OMS = 2   /* c2v = s * (relu(min - beta) - a_c) neural_2d_decoder.py:400-401                          */
+};
+
+typedef struct ldpc_graph ldpc_graph;      /* Tanner graph, CSR + CSC, device resident */
+typedef struct ldpc_decoder ldpc_decoder;  /* graph + weight tables + quantiser LUTs    */
+
+/* Replaces the reference's per-node dense scans `np.where(H[i,:]==1)` /
+ * `np.where(H[:,j]==1)` (ldpc_decoder.py:92,124).  Input is the CSR edge list
+ * (host memory): check i owns edges check_ptr[i]..check_ptr[i+1]-1, var_idx[e]
+ * ascending inside a check.  The CSC permutation is derived inside. */
+int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t n_edges,
+                      const int32_t *check_ptr, const int32_t *var_idx);
+void ldpc_graph_destroy(ldpc_graph *g);
+/* n, m, E, max check degree, max variable degree */
+int ldpc_graph_info(const ldpc_graph *g, int32_t out5[5]);
+
+/* All pointers are HOST pointers, copied at creation.  Weight tables are
+ * dtype-typed ([iters][slots], row t = iteration t); slot arrays say which
+ * table column an edge / a variable uses -- the flattened form of
+ * _get_beta_weight/_get_alpha_weight (neural_2d_decoder.py:84-131). */
+typedef struct {
+    int32_t dtype;              /* LDPC_F32 | LDPC_F64                                     */
+    int32_t c2v_form;           /* LDPC_C2V_*                                              */
+    int32_t iters;              /* T = max_iterations                                      */
+    int32_t n_beta_slots;
+    const void *beta;           /* [T][n_beta_slots]                                       */
+    const int32_t *beta_slot;   /* [E] per CSR edge                                        */
+    int32_t n_alpha_slots;
+    const void *alpha;          /* [T][n_alpha_slots]  V2C weight: llr + alpha * sum       */
+    const int32_t *alpha_slot;  /* [n] per variable                                        */
+    /* RCQ only: NonUniformQuantizer tables (rcq_decoder.py:48-57) as float32(tau)  */
+    int32_t n_levels;           /* 2^(bc-1), <= 128                                        */
+    int32_t n_quantizers;
+    const float *thresholds;    /* [n_quantizers][n_levels]                                */
+    const int32_t *q_of_iter;   /* [T] quantiser used in iteration t (rcq_decoder.py:156-167) */
+    /* OMS only: check-side offset alpha (neural_2d_decoder.py:392,400)              */
+    int32_t n_oms_alpha_slots;
+    const void *oms_alpha;      /* [T][n_oms_alpha_slots] or NULL (= 0)                    */
+    const int32_t *oms_alpha_slot; /* [E]                                                  */
+} ldpc_decoder_desc;
+
+int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc);
+/* re-upload beta/alpha(/oms_alpha) tables of an existing decoder (same shapes);
+ * enqueued on `stream`, host arrays must stay valid until it has run. */
+int ldpc_decoder_set_weights(ldpc_decoder *d, const void *beta, const void *alpha,
+                             const void *oms_alpha, void *stream);
+void ldpc_decoder_destroy(ldpc_decoder *d);
+
+/* bytes of device scratch ldpc_decode needs for a batch of `batch` codewords */
+size_t ldpc_decoder_workspace_bytes(const ldpc_decoder *d, int64_t batch);
+
+/* Decode llr[batch][n] (device, row-major, dtype of the decoder).
+ *   early_stop != 0 : reference semantics per codeword -- outputs are those of the
+ *                     first iteration whose syndrome is zero (iterations 1-based,
+ *                     success 1), else of iteration T (success 0);
+ *   early_stop == 0 : exactly T iterations; success = final syndrome is zero.
+ * Outputs (device, any may be NULL):
+ *   bits[batch][n] int32 (posterior < 0), posterior[batch][n] dtype,
+ *   iterations[batch] int32, success[batch] uint8,
+ *   packed_bits[batch][ceil(n/8)] uint8, bit j of a codeword at byte j/8, bit j%8
+ *   (wire format of the multi-GPU all-gather). */
+int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop,
+                int32_t *bits, void *posterior, int32_t *iterations, uint8_t *success,
+                uint8_t *packed_bits, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Run ONE sweep of iteration `iter` on the state left in `workspace` by a previous
+ * ldpc_decode of the same batch: which = 0 check-node (CN->VN) sweep, 1 variable-node
+ * sweep.  Measurement hook for bench.py's roofline leg (HIP events around a single
+ * kernel); never needed for decoding. */
+int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_t iter,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Byte offsets of the state arrays inside a workspace for `batch` codewords (test and
+ * measurement hook): out8 = { VEC, tiles, llrT, v2c, c2v, postT, bitsT, done }.  Messages
+ * are laid out [tile][edge][W] with W = 64*VEC codewords innermost. */
+int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8]);
+
+const char *ldpc_last_error(void);
+int ldpc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */
