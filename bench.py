@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""
+bench.py -- decoded codewords/s at fixed iterations + HBM roofline of the CN->VN sweep.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload basic|neural2d|rcq|wrcq_dvbs2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = ONE decode of one batch of synthetic LLRs (already resident in HBM) through the
+hot path: layout change, T x (check sweep + variable sweep), syndrome, hard decisions out.
+Default workload = BASELINE.json configs[1]: (1998,1512) code, BasicMinSumDecoder factor 0.7,
+fp32, 10 iterations, batch 65536 per GPU, SNR 2.0 dB, fixed iterations (early_stop=False).
+N > 1: weak scaling, every rank decodes its own 65536 codewords and the step ends with the
+RCCL all-gather of the bit-packed hard decisions; value = all ranks' codewords / max-rank time.
+
+Prints ONE JSON line (rank 0) with the driver's fields plus
+  roofline     : the check-node sweep kernel timed live with HIP events on its stream,
+                 ALGORITHMIC bytes (8E per codeword fp32, 5E RCQ) / time vs 8 TB/s
+  cpu_baseline : the CPU oracle (C port of the reference loops) on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, "implementation-of-neural-ldpc-decoders-with-degree-specific-weight-sharing-and-rcq-quantization_amd")
+for p in (PKG_DIR, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable)
+QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
+
+WORKLOADS = {
+    # name: (graph, iterations, default batch per GPU, description)
+    "basic": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, BasicMinSumDecoder factor=0.7, fp32"),
+    "neural2d": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, Neural2DMinSumDecoder type 2, fp32"),
+    "rcq": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, RCQMinSumDecoder bc=3 bv=8, 3 quantisers"),
+    "wrcq_dvbs2": ("dvbs2_like_16200_7200", 20, 32768, "(16200,7200) DVB-S2-like code, WeightedRCQDecoder type 2 bc=3"),
+}
+
+
+def synthetic_tables(dec, seed=4321):
+    """'pretrained' weights stand-in: beta ~ U(0.5,1), alpha ~ U(0.8,1.2)"""
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for k in sorted(dec.beta_weights.keys()):
+            dec.beta_weights[k].fill_(float(np.float32(rng.uniform(0.5, 1.0))))
+        for k in sorted(dec.alpha_weights.keys()):
+            dec.alpha_weights[k].fill_(float(np.float32(rng.uniform(0.8, 1.2))))
+
+
+def build_decoder(workload, device):
+    """-> (engine, host decoder, graph, oracle call for the CPU baseline)"""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder, WeightedRCQDecoder
+    gname, T, _, _ = WORKLOADS[workload]
+    code = codes.load_code(gname, max_iterations=T)
+    if workload == "basic":
+        dec = BasicMinSumDecoder(code, factor=0.7)
+        eng = dec._engine(torch.float32, device)
+    elif workload == "neural2d":
+        dec = Neural2DMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+        synthetic_tables(dec)
+        eng = dec._get_engine(device)
+    elif workload == "rcq":
+        dec = RCQMinSumDecoder(code, bc=3, bv=8, quantizer_params=QP, max_iterations=T)
+        eng = dec._get_engine(device)
+    else:
+        dec = WeightedRCQDecoder(code, bc=3, bv=8, quantizer_params=QP, weight_sharing_type=2, max_iterations=T)
+        synthetic_tables(dec)
+        eng = dec._get_engine(device)
+    return eng, dec, code
+
+
+def make_llr(batch, n, snr_db, seed, device):
+    """all-zero codeword, decoder convention (+LLR = bit 0): llr = 2(1 + sigma z)/sigma^2"""
+    s2 = 10.0 ** (-snr_db / 10.0)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    z = torch.randn((batch, n), generator=gen, device=device, dtype=torch.float32)
+    return (2.0 * (1.0 + (s2 ** 0.5) * z) / s2).contiguous()
+
+
+def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
+    """The CPU oracle (oracle/ldpc_oracle.c, a C port of the reference's loops; the Python
+    reference itself cannot travel to the GPU box) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    oracle.build()
+    g = code.tanner_graph()
+    og = oracle.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    T = WORKLOADS[workload][1]
+    rng = np.random.default_rng(1234)
+    s2 = 10.0 ** (-snr_db / 10.0)
+    threads = oracle.num_threads()
+
+    def run(cnt):
+        x = (2.0 * (1.0 + np.sqrt(s2) * rng.standard_normal((cnt, g.n))) / s2).astype(np.float32)
+        t0 = time.perf_counter()
+        if workload == "basic":
+            oracle.basic_minsum(og, x, 0.7, T, early_stop=False, dtype=np.float32)
+        elif workload == "neural2d":
+            oracle.neural2d(og, x, 2, T, {k: float(v.item()) for k, v in dec.beta_weights.items()},
+                            {k: float(v.item()) for k, v in dec.alpha_weights.items()}, early_stop=False)
+        elif workload == "rcq":
+            oracle.rcq(og, x, 3, QP, T, early_stop=False)
+        else:
+            oracle.weighted_rcq(og, x, 3, QP, 2, T, {k: float(v.item()) for k, v in dec.beta_weights.items()},
+                                {k: float(v.item()) for k, v in dec.alpha_weights.items()}, early_stop=False)
+        return time.perf_counter() - t0
+
+    probe = max(threads * 2, 8)
+    t_probe = run(probe)
+    cnt = int(max(probe, min(65536, probe * budget_s / max(t_probe, 1e-6))))
+    t = run(cnt)
+    return {"value": cnt / t, "unit": "codewords/s", "cores": threads, "kind": "port",
+            "sample": f"{cnt} codewords of the same workload, fixed {T} iterations, OpenMP over codewords, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="basic")
+    ap.add_argument("--batch", type=int, default=0, help="codewords per GPU (default: the workload's)")
+    ap.add_argument("--snr-db", type=float, default=2.0)
+    ap.add_argument("--early-stop", action="store_true", help="reference early-exit semantics instead of fixed T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the decode path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+
+    gname, T, default_batch, desc = WORKLOADS[args.workload]
+    B = args.batch or default_batch
+    eng, dec, code = build_decoder(args.workload, device)
+    g = code.tanner_graph()
+    llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device)
+    want_post = args.workload in ("neural2d", "wrcq_dvbs2")      # those decoders return the posterior
+    early = bool(args.early_stop)
+
+    from sharding import all_gather_hard_decisions
+
+    def step():
+        res = eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post, want_packed=world > 1)
+        if world > 1:
+            return res, all_gather_hard_decisions(res.packed_bits, B * world)
+        return res, None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, gathered = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+
+    # sanity on the last step's outputs (nothing skipped): all iterations ran, outputs are binary
+    its = res.iterations
+    assert int(its.min().item()) >= 1 and int(its.max().item()) <= T
+    if not early:
+        assert int(its.min().item()) == T
+    frac_ok = float(res.success.float().mean().item())
+
+    out = {
+        "metric": "decoded codewords/sec at fixed iters; achieved HBM GB/s vs peak",
+        "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{desc}, {T} iterations, batch {B}/GPU, SNR {args.snr_db} dB, "
+                               f"{'early-stop' if early else 'fixed-iteration'} flooding decode",
+                   "graph": gname, "n": g.n, "m": g.m, "edges": g.E, "iterations": T,
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "collective": "all_gather(bit-packed hard decisions)" if world > 1 else "none",
+                   "converged_fraction": frac_ok},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the check-node (CN->VN) sweep, timed live with HIP
+        # events on the stream it is launched on (torch's current stream).
+        reps = max(args.sweep_reps, 1)
+        rcq_like = args.workload in ("rcq", "wrcq_dvbs2")
+        bytes_cn = (5 if rcq_like else 8) * g.E * B            # read v2c 4E + write c2v 4E (1E as codes)
+        bytes_vn = ((5 if rcq_like else 8) * g.E + 4 * g.n) * B
+        times = {}
+        for which, name in ((0, "cn_sweep"), (1, "vn_sweep")):
+            for _ in range(3):
+                eng.debug_sweep(B, which, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                eng.debug_sweep(B, which, 1)
+            e1.record()
+            e1.synchronize()
+            times[name] = e0.elapsed_time(e1) / reps            # ms per launch
+        achieved = bytes_cn / (times["cn_sweep"] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(args.workload, {}).get("cn_sweep_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": bytes_cn, "ms_per_launch": times["cn_sweep"],
+                           "vn_sweep": {"ms_per_launch": times["vn_sweep"],
+                                        "achieved": bytes_vn / (times["vn_sweep"] * 1e-3) / 1e9,
+                                        "algorithmic_bytes_per_launch": bytes_vn}}
+        per_decode = (T * ((10 if rcq_like else 16) * g.E + 4 * g.n) + 8 * g.n) * B
+        out["decode_algorithmic_GBps"] = per_decode / (ms_per_step * 1e-3) / 1e9
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

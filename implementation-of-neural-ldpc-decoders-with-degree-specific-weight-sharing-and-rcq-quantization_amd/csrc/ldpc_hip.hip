@@ -80,6 +80,7 @@ struct ldpc_decoder {
     float *thresholds = nullptr;   // device [Q][L]
     float *lut = nullptr;          // device [Q][2L] signed reconstruction values
     std::vector<int> q_of_iter;    // host
+    int *q_of_iter_dev = nullptr;  // device copy (frozen codewords look their quantiser up)
     size_t elem() const { return dtype == LDPC_F64 ? 8 : 4; }
 };
 
@@ -174,13 +175,16 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
     const int row = it < d->T ? it : 0;     // T == 0: posterior-only pass, alpha unused
     const T *alpha_row = (const T *)d->alpha + (size_t)row * d->n_alpha;
     const bool codes = d->form == LDPC_C2V_RCQ;
-    const float *lut = codes ? d->lut + (size_t)d->q_of_iter[row] * 2 * d->n_levels : nullptr;
-    const int lut_size = codes ? 2 * d->n_levels : 0;
+    const int lut_stride = 2 * d->n_levels;
+    const int lut_total = codes ? d->n_quant * lut_stride : 0;
+    const int lut_cur = codes ? d->q_of_iter[row] * lut_stride : 0;
+    const size_t shmem = (size_t)lut_total * sizeof(float);
     const uint64_t *done = use_done ? w.done : nullptr;
 #define LDPC_VN(CODES, LAST)                                                                           \
-    hipLaunchKernelGGL((vn_sweep<T, VEC, CODES, LAST>), grid, block, 0, s, g, (const void *)w.c2v,      \
-                       (const T *)w.llrT, (T *)w.v2c, alpha_row, d->alpha_slot, lut, lut_size, w.bitsT, \
-                       (T *)w.postT, done, vb)
+    hipLaunchKernelGGL((vn_sweep<T, VEC, CODES, LAST>), grid, block, shmem, s, g, (const void *)w.c2v,  \
+                       (const T *)w.llrT, (T *)w.v2c, alpha_row, d->alpha_slot, (const float *)d->lut,  \
+                       lut_total, lut_cur, lut_stride, (const int *)d->q_of_iter_dev,                   \
+                       (const int *)w.iters, w.bitsT, (T *)w.postT, done, vb)
     if (codes) {
         if constexpr (sizeof(T) == 4) {
             if (last) LDPC_VN(true, true); else LDPC_VN(true, false);
@@ -416,6 +420,8 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
                 lut[q * 2 * L + c] = (1.0f - 2.0f * sb) * desc->thresholds[q * L + (c % L)];
             }
         if (!rc) rc = upload(&d->lut, lut.data(), lut.size());
+        if (!rc) rc = upload(&d->q_of_iter_dev, d->q_of_iter.data(), d->q_of_iter.size());
+        if (!rc && Q * 2 * L * sizeof(float) > 64 * 1024) rc = fail(LDPC_ERR_UNSUPPORTED, "quantiser LUTs exceed 64 KiB of LDS");
     }
     if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha && d->T > 0) {
         d->n_oms_alpha = desc->n_oms_alpha_slots;
@@ -453,7 +459,7 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
     DeviceGuard guard(d->g->device);
     (void)hipFree(d->beta); (void)hipFree(d->alpha); (void)hipFree(d->oms_alpha);
     (void)hipFree(d->beta_slot); (void)hipFree(d->alpha_slot); (void)hipFree(d->oms_alpha_slot);
-    (void)hipFree(d->thresholds); (void)hipFree(d->lut);
+    (void)hipFree(d->thresholds); (void)hipFree(d->lut); (void)hipFree(d->q_of_iter_dev);
     delete d;
 }
 

@@ -364,14 +364,24 @@ __device__ __forceinline__ Pack<T, VEC> sum_rt(int N, Get get)
 // (CSC order), forms the dv leave-one-out sums and the posterior in the reference's
 // association order, writes dv V2C rows, the hard-decision ballots and (LAST) the posterior.
 // ------------------------------------------------------------------------------------------
+// Reconstruction LUTs of ALL quantisers sit in LDS ([Q][2L] signed values); `off[c]` selects
+// the table a codeword uses.  It is the current iteration's quantiser, except in the LAST
+// sweep for codewords the early-stop latch froze earlier: their codes were produced by the
+// quantiser of the iteration they stopped in and must be reconstructed with that one.
+template <int VEC>
+struct Lut {
+    const float *base;
+    int off[VEC];
+};
+
 template <typename T, int VEC, bool CODES>
-__device__ __forceinline__ Pack<T, VEC> load_c2v(const void *c2v, size_t elem_off, const float *lut)
+__device__ __forceinline__ Pack<T, VEC> load_c2v(const void *c2v, size_t elem_off, const Lut<VEC> &lut)
 {
     if constexpr (CODES) {
         Pack<uint8_t, VEC> q = ld<uint8_t, VEC>(reinterpret_cast<const uint8_t *>(c2v) + elem_off);
         Pack<T, VEC> r;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) r.x[c] = (T)lut[q.x[c]];   // reconstruction LUT in LDS
+        for (int c = 0; c < VEC; ++c) r.x[c] = (T)lut.base[lut.off[c] + q.x[c]];
         return r;
     } else {
         return ld<T, VEC>(reinterpret_cast<const T *>(c2v) + elem_off);
@@ -381,7 +391,7 @@ __device__ __forceinline__ Pack<T, VEC> load_c2v(const void *c2v, size_t elem_of
 template <typename T, int VEC, bool CODES, int ORDER, bool LAST, int DV>
 __device__ __forceinline__ void vn_body(const GraphDev &g, int tile, int j, int s0, int lane,
                                         const void *__restrict__ c2v, const T *__restrict__ llrT,
-                                        T *__restrict__ v2c, T a, const float *lut,
+                                        T *__restrict__ v2c, T a, const Lut<VEC> &lut,
                                         uint64_t *__restrict__ bitsT, T *__restrict__ postT,
                                         const Frozen<VEC> &fz)
 {
@@ -432,7 +442,7 @@ __device__ __forceinline__ void vn_body(const GraphDev &g, int tile, int j, int 
 template <typename T, int VEC, bool CODES, int ORDER, bool LAST>
 __device__ __noinline__ void vn_generic(const GraphDev &g, int tile, int j, int s0, int dv, int lane,
                                         const void *__restrict__ c2v, const T *__restrict__ llrT,
-                                        T *__restrict__ v2c, T a, const float *lut,
+                                        T *__restrict__ v2c, T a, const Lut<VEC> &lut,
                                         uint64_t *__restrict__ bitsT, T *__restrict__ postT,
                                         const Frozen<VEC> &fz)
 {
@@ -469,14 +479,18 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
                                                    const T *__restrict__ llrT, T *__restrict__ v2c,
                                                    const T *__restrict__ alpha_row,
                                                    const int *__restrict__ alpha_slot,
-                                                   const float *__restrict__ lut_global, int lut_size,
+                                                   const float *__restrict__ lut_global, int lut_total,
+                                                   int lut_cur_off, int lut_stride,
+                                                   const int *__restrict__ q_of_iter,
+                                                   const int *__restrict__ iters_ws,
                                                    uint64_t *__restrict__ bitsT, T *__restrict__ postT,
                                                    const uint64_t *__restrict__ done, int var_blocks)
 {
     constexpr int ORDER = sizeof(T) == 8 ? 1 : 0;   // fp64 = numpy decoder, fp32 = torch decoders
-    __shared__ float lut[256];
+    constexpr int W = kWave * VEC;
+    extern __shared__ float lut_s[];
     if (CODES) {
-        if ((int)threadIdx.x < lut_size) lut[threadIdx.x] = lut_global[threadIdx.x];
+        for (int k = threadIdx.x; k < lut_total; k += kBlock) lut_s[k] = lut_global[k];
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1);
@@ -490,6 +504,16 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
     const bool all_frozen = load_frozen<VEC>(done, tile, lane, fz);
     if (!LAST && all_frozen) return;    // LAST still has to publish the latched posterior
     const T a = alpha_row[alpha_slot[j]];
+    Lut<VEC> lut;
+    lut.base = lut_s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        lut.off[c] = lut_cur_off;
+        if (CODES && LAST && done && fz.one(c)) {
+            const int it = iters_ws[(size_t)tile * W + lane * VEC + c];      // 1-based stop iteration
+            lut.off[c] = q_of_iter[it > 0 ? it - 1 : 0] * lut_stride;
+        }
+    }
 
 #define LDPC_VN_CASE(D) \
     case D: vn_body<T, VEC, CODES, ORDER, LAST, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut, bitsT, postT, fz); break;
