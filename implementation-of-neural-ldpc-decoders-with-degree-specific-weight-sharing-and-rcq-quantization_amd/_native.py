@@ -19,7 +19,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libldpc_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # override: A/B kernel variants
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip.h")
 
@@ -35,21 +35,23 @@ class NativeEngineError(RuntimeError):
     pass
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir."""
+def build_native(force: bool = False, verbose: bool = False, defines=(), out: Optional[str] = None) -> str:
+    """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir.
+    `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
     srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"), HEADER]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
+    target = out or os.path.join(_HERE, LIB_NAME)
+    if not force and os.path.exists(target) and all(
+            os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
+        return target
     hipcc = os.environ.get("HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
+    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", target, srcs[0]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
         print(res.stdout + res.stderr)
     if res.returncode != 0:
         raise NativeEngineError("hipcc failed:\n" + res.stderr[-4000:])
-    return LIB_PATH
+    return target
 
 
 class DecoderDesc(C.Structure):

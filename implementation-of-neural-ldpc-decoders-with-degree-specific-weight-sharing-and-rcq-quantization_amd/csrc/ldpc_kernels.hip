@@ -40,15 +40,41 @@ struct alignas(sizeof(T) * V) Pack {
     T x[V];
 };
 
+// Message rows are streamed exactly once per sweep (a sweep moves GBs, far beyond the 256 MiB
+// Infinity Cache), so loads/stores may carry the non-temporal hint; knobs for A/B timing.
+#ifndef LDPC_NT_LOAD
+#define LDPC_NT_LOAD 1
+#endif
+#ifndef LDPC_NT_STORE
+#define LDPC_NT_STORE 1
+#endif
+#ifndef LDPC_CN_UNROLL
+#define LDPC_CN_UNROLL 4
+#endif
+
 template <typename T, int V>
 __device__ __forceinline__ Pack<T, V> ld(const T *p)
 {
-    return *reinterpret_cast<const Pack<T, V> *>(p);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    union { VT v; Pack<T, V> k; } u;
+#if LDPC_NT_LOAD
+    u.v = __builtin_nontemporal_load(reinterpret_cast<const VT *>(p));
+#else
+    u.v = *reinterpret_cast<const VT *>(p);
+#endif
+    return u.k;
 }
 template <typename T, int V>
 __device__ __forceinline__ void st(T *p, const Pack<T, V> &v)
 {
-    *reinterpret_cast<Pack<T, V> *>(p) = v;
+    typedef T VT __attribute__((ext_vector_type(V)));
+    union { VT v; Pack<T, V> k; } u;
+    u.k = v;
+#if LDPC_NT_STORE
+    __builtin_nontemporal_store(u.v, reinterpret_cast<VT *>(p));
+#else
+    *reinterpret_cast<VT *>(p) = u.v;
+#endif
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
         m1[c] = inf_of<T>(); m2[c] = inf_of<T>(); idx[c] = 0; sm[c] = 0; zm[c] = 0; par[c] = 0; nz[c] = 0;
     }
 
-#pragma unroll 4
+#pragma unroll LDPC_CN_UNROLL
     for (int t = 0; t < dc; ++t) {
         const T *row = FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W;
         Pack<T, VEC> v = ld<T, VEC>(row);
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     }
     OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
 
-#pragma unroll 4
+#pragma unroll LDPC_CN_UNROLL
     for (int t = 0; t < dc; ++t) {
         const T b = beta_row[beta_slot[e0 + t]];
         T oa = (T)0;
@@ -440,7 +466,7 @@ __device__ __forceinline__ void vn_body(const GraphDev &g, int tile, int j, int 
 }
 
 template <typename T, int VEC, bool CODES, int ORDER, bool LAST>
-__device__ __noinline__ void vn_generic(const GraphDev &g, int tile, int j, int s0, int dv, int lane,
+__device__ __forceinline__ void vn_generic(const GraphDev &g, int tile, int j, int s0, int dv, int lane,
                                         const void *__restrict__ c2v, const T *__restrict__ llrT,
                                         T *__restrict__ v2c, T a, const Lut<VEC> &lut,
                                         uint64_t *__restrict__ bitsT, T *__restrict__ postT,

@@ -1,0 +1,148 @@
+"""
+GPU tests at BASELINE.json's full sizes (batch 65536 on the (1998,1512) code, 32768 on the
+(16200,7200) code) through size-independent properties, plus oracle spot checks of rows
+sampled from the big batch:
+
+  * row independence: rows of a 65536-batch equal the oracle's single-codeword results
+  * sign symmetry of min-sum: decoding llr*(1-2c) for a codeword c gives bits XOR c and
+    posterior*(1-2c), same iteration count (exact in floating point: every operation is odd)
+  * success  <=>  H @ bits == 0 (mod 2); iterations within [1, T]; packed bits == bits
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
+
+
+def awgn_gpu(B, n, snr_db, seed, dev):
+    s2 = 10.0 ** (-snr_db / 10.0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    z = torch.randn((B, n), generator=gen, device=dev, dtype=torch.float32)
+    return 2.0 * (1.0 + (s2 ** 0.5) * z) / s2
+
+
+def dense_H(graph, dev):
+    return torch.from_numpy(graph.to_dense(np.float32)).to(dev)
+
+
+def ira_encode(graph, u, dev):
+    """systematic IRA encoding on the committed staircase codes: p_i = p_{i-1} + (H_info u)_i
+    (torch on the GPU as plain test plumbing; counts stay far below 2^24 so fp32 is exact)"""
+    k = graph.n - graph.m
+    H = dense_H(graph, dev)
+    u = torch.from_numpy(u).to(dev).float()
+    s = torch.remainder(u @ H[:, :k].T, 2)
+    p = torch.remainder(torch.cumsum(s, dim=1), 2)
+    cw = torch.cat([u, p], dim=1)
+    assert not bool(torch.remainder(cw @ H.T, 2).any())
+    return cw.to(torch.int32)
+
+
+def syndrome_ok(graph, bits):
+    """bits: int tensor [B, n] on the GPU (or numpy) -> numpy bool[B], True where H @ bits == 0 mod 2"""
+    if not isinstance(bits, torch.Tensor):
+        return ~(graph.syndrome(bits).any(axis=-1))
+    H = dense_H(graph, bits.device)
+    return (~torch.remainder(bits.float() @ H.T, 2).bool().any(dim=1)).cpu().numpy()
+
+
+def test_basic_65536_rows_match_oracle_and_properties(gpu_device, oracle_mod):
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    B = 65536
+    code = codes.load_code("ira_1998_1512", 10)
+    g = code.tanner_graph()
+    dec = BasicMinSumDecoder(code, 0.7)
+    eng = dec._engine(torch.float32, gpu_device)
+    llr = torch.cat([awgn_gpu(B // 2, g.n, 2.0, 1, gpu_device), awgn_gpu(B // 2, g.n, 4.5, 2, gpu_device)])
+    llr = llr[torch.randperm(B, device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(3))]
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    rng = np.random.default_rng(0)
+    rows = np.unique(np.r_[0, 255, 256, B - 1, rng.integers(0, B, 120)])
+    for early in (True, False):
+        res = eng.decode(llr, early_stop=early, want_packed=True)
+        bits = res.bits.cpu().numpy()
+        iters = res.iterations.cpu().numpy()
+        succ = res.success.cpu().numpy()
+        assert iters.min() >= 1 and iters.max() <= 10
+        if early:
+            assert len(np.unique(iters)) >= 4                    # codewords of one wave stop at different times
+            np.testing.assert_array_equal(succ, syndrome_ok(g, res.bits))
+            assert np.all(iters[~succ] == 10)
+        else:
+            assert np.all(iters == 10)
+            np.testing.assert_array_equal(succ, syndrome_ok(g, res.bits))
+        ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr[rows].cpu().numpy(), 0.7, 10, early_stop=early, dtype=np.float32)
+        np.testing.assert_array_equal(bits[rows], ob)
+        np.testing.assert_array_equal(iters[rows], oi)
+        np.testing.assert_array_equal(succ[rows], os_)
+        np.testing.assert_allclose(res.posterior[rows].cpu().numpy(), op, rtol=1e-5, atol=1e-5)
+        packed = res.packed_bits.cpu().numpy()
+        unpacked = ((packed[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :g.n]
+        np.testing.assert_array_equal(unpacked, bits)
+
+
+@pytest.mark.parametrize("family", ["neural2d", "rcq"])
+def test_sign_symmetry_at_full_batch(family, gpu_device):
+    import codes
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder
+    B = 65536
+    code = codes.load_code("ira_1998_1512", 10)
+    g = code.tanner_graph()
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 2, (B, g.n - g.m))
+    cw = ira_encode(g, u, gpu_device)
+    sgn = (1 - 2 * cw).to(torch.float32)
+    llr = awgn_gpu(B, g.n, 4.0, 11, gpu_device)
+    if family == "neural2d":
+        dec = Neural2DMinSumDecoder(code, 2, 10)
+        with torch.no_grad():
+            for k, p in dec.beta_weights.items():
+                p.fill_(0.6 + 0.03 * (hash(k) % 10))
+            for k, p in dec.alpha_weights.items():
+                p.fill_(0.9 + 0.02 * (hash(k) % 10))
+        eng = dec._get_engine(gpu_device)
+    else:
+        eng = RCQMinSumDecoder(code, 3, 8, QP, 10)._get_engine(gpu_device)
+    a = eng.decode(llr, early_stop=True)
+    b = eng.decode(llr * sgn, early_stop=True)
+    assert torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
+    assert torch.equal(b.bits, a.bits ^ cw.to(torch.int32))
+    assert torch.equal(b.posterior, a.posterior * sgn)
+    assert float(a.success.float().mean()) > 0.5               # the early-stop latch was exercised
+
+
+def test_dvbs2_wrcq_32768_properties(gpu_device, oracle_mod):
+    """config 5's per-GPU shard: (16200,7200), W-RCQ type 2, T=20, 32768 codewords"""
+    import codes
+    from rcq_decoder import WeightedRCQDecoder
+    B = 32768
+    code = codes.load_code("dvbs2_like_16200_7200", 20)
+    g = code.tanner_graph()
+    dec = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=2, max_iterations=20)
+    rng = np.random.default_rng(4321)
+    with torch.no_grad():
+        for k in sorted(dec.beta_weights.keys()):
+            dec.beta_weights[k].fill_(float(np.float32(rng.uniform(0.5, 1.0))))
+        for k in sorted(dec.alpha_weights.keys()):
+            dec.alpha_weights[k].fill_(float(np.float32(rng.uniform(0.8, 1.2))))
+    beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+    alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+    eng = dec._get_engine(gpu_device)
+    llr = torch.cat([awgn_gpu(B // 2, g.n, 2.0, 7, gpu_device), awgn_gpu(B // 2, g.n, 5.0, 8, gpu_device)])
+    res = eng.decode(llr, early_stop=True)
+    iters = res.iterations.cpu().numpy()
+    succ = res.success.cpu().numpy()
+    assert iters.min() >= 1 and iters.max() <= 20
+    rows = np.r_[0, B // 2 - 1, B // 2, B - 1, np.random.default_rng(1).integers(0, B, 12)]
+    bits = res.bits[rows].cpu().numpy()
+    np.testing.assert_array_equal(succ[rows], syndrome_ok(g, bits))
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    ob, op, oi, _ = oracle_mod.weighted_rcq(og, llr[rows].cpu().numpy(), 3, QP, 2, 20, beta, alpha)
+    np.testing.assert_array_equal(bits, ob)
+    np.testing.assert_array_equal(iters[rows], oi)
+    np.testing.assert_array_equal(res.posterior[rows].cpu().numpy(), op)

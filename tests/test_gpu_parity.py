@@ -121,23 +121,6 @@ def test_neural2d_toy_golden(wtype, gpu_device):
         check_neural(dec, sub, gpu_device)
 
 
-def test_neural2d_default_init_matches_reference_rng():
-    """same seed -> same randn*0.1 parameters as the reference constructor (CPU-only logic,
-    kept here because the golden block it reads belongs to this file's fixtures)"""
-    from neural_2d_decoder import Neural2DMinSumDecoder
-    g = load_golden("toy_neural2d")
-    for wtype in (1, 2, 3, 4):
-        sub = golden_sub(g, f"t{wtype}d")
-        torch.manual_seed(100 + wtype)
-        dec = Neural2DMinSumDecoder(make_code({"H": g["H"]}, 10), weight_sharing_type=wtype, max_iterations=10)
-        want = weights_dict(sub["beta_keys"], sub["beta_vals"])
-        got = {k: float(v.item()) for k, v in dec.beta_weights.items()}
-        assert got == want
-        want = weights_dict(sub["alpha_keys"], sub["alpha_vals"])
-        got = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
-        assert got == want
-
-
 @pytest.mark.parametrize("wtype", [1, 2, 3, 4])
 def test_neural2d_small_golden(wtype, gpu_device):
     from neural_2d_decoder import Neural2DMinSumDecoder

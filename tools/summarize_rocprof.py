@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/, scratch) into the small tracked
+summaries under profiles/.
+
+    python tools/summarize_rocprof.py <round-tag> <workload> <stats_dir> [<fetch_dir> <write_dir>]
+
+Writes profiles/<tag>_<workload>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, every
+kernel of the timed command) and, when the two PMC passes are given, profiles/<tag>_<workload>_pmc.csv
+plus the per-launch HBM bytes of the sweep kernels into profiles/traffic.json.
+gfx950 correction (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are in KiB;
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read,
+so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for the message sweeps.
+"""
+import collections, csv, glob, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return re.sub(r"\(.*", "", name)
+
+
+def main():
+    tag, workload, stats_dir = sys.argv[1:4]
+    os.makedirs(PROF, exist_ok=True)
+    f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    out = os.path.join(PROF, f"{tag}_{workload}_kernel_stats.csv")
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    print("wrote", out)
+    if len(sys.argv) >= 6:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for d in sys.argv[4:6]:
+            f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+            for r in csv.DictReader(open(f)):
+                if "ldpc::" in r["Kernel_Name"]:
+                    agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out = os.path.join(PROF, f"{tag}_{workload}_pmc.csv")
+        traffic = {}
+        with open(out, "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Kernel", "Launches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "hbm_bytes_per_launch_corrected"])
+            for k, c in sorted(agg.items()):
+                fe = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
+                wr = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+                hbm = (2 * fe + wr) * 1024
+                w.writerow([k, len(c["FETCH_SIZE"]), f"{fe:.1f}", f"{wr:.1f}", f"{hbm:.0f}"])
+                traffic[k] = hbm
+        print("wrote", out)
+        tj = os.path.join(PROF, "traffic.json")
+        data = json.load(open(tj)) if os.path.exists(tj) else {}
+        cn = [v for k, v in traffic.items() if k.startswith("ldpc::cn_sweep") and k.rstrip(">").endswith("false")]
+        vn = [v for k, v in traffic.items() if k.startswith("ldpc::vn_sweep") and k.rstrip(">").endswith("false")]
+        data[workload] = {"cn_sweep_bytes_per_launch": cn[0] if cn else None,
+                          "vn_sweep_bytes_per_launch": vn[0] if vn else None,
+                          "source": f"{tag}_{workload}_pmc.csv", "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+        json.dump(data, open(tj, "w"), indent=1)
+        print("wrote", tj)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Time one decode and the individual CN / VN sweeps of a workload with HIP events.
+Used for A/B timing of kernel variants: LDPC_HIP_LIB=<variant .so> python tools/time_sweeps.py"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="basic")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--tag", default=os.environ.get("LDPC_HIP_LIB", "default"))
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    gname, T, B0, _ = bench.WORKLOADS[a.workload]
+    B = a.batch or B0
+    eng, dec, code = bench.build_decoder(a.workload, dev)
+    llr = bench.make_llr(B, code.n, 2.0, 1234, dev)
+    for _ in range(2):
+        eng.decode(llr, early_stop=False, want_posterior=False)
+    torch.cuda.synchronize()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        eng.decode(llr, early_stop=False, want_posterior=False)
+    e1.record(); e1.synchronize()
+    out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5}
+    for which, name in ((0, "cn_ms"), (1, "vn_ms")):
+        for _ in range(3):
+            eng.debug_sweep(B, which, 1)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(a.reps):
+            eng.debug_sweep(B, which, 1)
+        e1.record(); e1.synchronize()
+        out[name] = e0.elapsed_time(e1) / a.reps
+    g = code.tanner_graph()
+    rcq = a.workload in ("rcq", "wrcq_dvbs2")
+    out["cn_GBs"] = (5 if rcq else 8) * g.E * B / out["cn_ms"] / 1e6
+    out["vn_GBs"] = ((5 if rcq else 8) * g.E + 4 * g.n) * B / out["vn_ms"] / 1e6
+    out["Mcw_s"] = B / out["decode_ms"] / 1e3
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
