@@ -97,7 +97,7 @@ def test_sign_symmetry_at_full_batch(family, gpu_device):
     u = rng.integers(0, 2, (B, g.n - g.m))
     cw = ira_encode(g, u, gpu_device)
     sgn = (1 - 2 * cw).to(torch.float32)
-    llr = awgn_gpu(B, g.n, 4.0, 11, gpu_device)
+    llr = torch.cat([awgn_gpu(B // 2, g.n, 5.5, 11, gpu_device), awgn_gpu(B // 2, g.n, 3.0, 12, gpu_device)])
     if family == "neural2d":
         dec = Neural2DMinSumDecoder(code, 2, 10)
         with torch.no_grad():
@@ -113,7 +113,7 @@ def test_sign_symmetry_at_full_batch(family, gpu_device):
     assert torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
     assert torch.equal(b.bits, a.bits ^ cw.to(torch.int32))
     assert torch.equal(b.posterior, a.posterior * sgn)
-    assert float(a.success.float().mean()) > 0.5               # the early-stop latch was exercised
+    assert float(a.success.float().mean()) > 0.2               # the early-stop latch was exercised
 
 
 def test_dvbs2_wrcq_32768_properties(gpu_device, oracle_mod):
