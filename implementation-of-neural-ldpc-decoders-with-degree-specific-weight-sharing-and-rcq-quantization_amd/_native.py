@@ -25,6 +25,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip.h")
 
 LDPC_F32, LDPC_F64 = 0, 1
 C2V_NMS, C2V_RCQ, C2V_OMS = 0, 1, 2
+MODE_AUTO, MODE_STREAM, MODE_RESIDENT = 0, 1, 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",       # the reference never fuses llr + alpha*sum
@@ -38,7 +39,8 @@ class NativeEngineError(RuntimeError):
 def build_native(force: bool = False, verbose: bool = False, defines=(), out: Optional[str] = None) -> str:
     """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir.
     `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
-    srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"), HEADER]
+    srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"),
+            os.path.join(CSRC, "ldpc_resident.hip"), HEADER]
     target = out or os.path.join(_HERE, LIB_NAME)
     if not force and os.path.exists(target) and all(
             os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
@@ -65,6 +67,7 @@ class DecoderDesc(C.Structure):
 
 # every symbol include/ldpc_hip.h declares (tests check the library exports them all)
 EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
+           "ldpc_decoder_set_mode", "ldpc_decoder_info",
            "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
            "ldpc_decode", "ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_last_error", "ldpc_abi_version")
 
@@ -97,6 +100,10 @@ def load():
         lib.ldpc_graph_info.argtypes = [vp, vp]
         lib.ldpc_decoder_create.restype = C.c_int
         lib.ldpc_decoder_create.argtypes = [C.POINTER(vp), vp, C.POINTER(DecoderDesc)]
+        lib.ldpc_decoder_set_mode.restype = C.c_int
+        lib.ldpc_decoder_set_mode.argtypes = [vp, i32]
+        lib.ldpc_decoder_info.restype = C.c_int
+        lib.ldpc_decoder_info.argtypes = [vp, vp]
         lib.ldpc_decoder_set_weights.restype = C.c_int
         lib.ldpc_decoder_set_weights.argtypes = [vp, vp, vp, vp, vp]
         lib.ldpc_decoder_destroy.restype = None

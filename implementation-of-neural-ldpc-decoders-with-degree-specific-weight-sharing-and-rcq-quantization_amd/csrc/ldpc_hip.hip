@@ -4,11 +4,13 @@
 // sequence of one decode.  Nothing here allocates or synchronises inside ldpc_decode
 // (graph-capturable); all work goes to the caller's stream.
 #include "ldpc_kernels.hip"
+#include "ldpc_resident.hip"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -68,6 +70,7 @@ struct ldpc_graph {
     int device = 0;
     int n = 0, m = 0, E = 0, max_dc = 0, max_dv = 0;
     int *check_ptr = nullptr, *var_idx = nullptr, *var_ptr = nullptr, *csc_edge = nullptr;
+    std::vector<int> h_check_ptr, h_var_idx, h_var_ptr, h_csc;   // host copies (resident-plan builder)
     GraphDev dev() const { return GraphDev{n, m, E, check_ptr, var_idx, var_ptr, csc_edge}; }
 };
 
@@ -82,6 +85,13 @@ struct ldpc_decoder {
     std::vector<int> q_of_iter;    // host
     int *q_of_iter_dev = nullptr;  // device copy (frozen codewords look their quantiser up)
     size_t elem() const { return dtype == LDPC_F64 ? 8 : 4; }
+    // LDS-resident engine (ldpc_resident.hip): built at creation when the code qualifies
+    int mode = 0;                  // LDPC_MODE_*
+    bool res_ok = false;
+    int res_G = 0, res_NT = 0;
+    size_t res_lds = 0;
+    ResidentPlan res{};
+    std::vector<void *> res_bufs;  // device allocations owned by the plan
 };
 
 namespace {
@@ -278,6 +288,129 @@ int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool 
     return fail(LDPC_ERR_ARG, "internal: bad tile width");
 }
 
+
+// ---- LDS-resident engine: plan (host) ---------------------------------------------------------
+constexpr size_t kLdsBytes = 160 * 1024 - 512;    // 160 KiB per CU minus static/alignment slack
+
+size_t resident_lds_bytes(int n, int S, int G) { return ((size_t)S + n) * G * sizeof(float) + (size_t)n + 16; }
+
+template <typename X>
+int plan_upload(ldpc_decoder *d, const X **dst, const std::vector<X> &src)
+{
+    X *p = nullptr;
+    int rc = upload(&p, src.data(), src.size());
+    if (rc) return rc;
+    d->res_bufs.push_back((void *)p);
+    *dst = p;
+    return LDPC_OK;
+}
+
+// Sort checks and variables by degree (stable, descending), lay the edges out ELL-transposed.
+int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
+{
+    const ldpc_graph *g = d->g;
+    d->res_ok = false;
+    if (d->dtype != LDPC_F32 || g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
+    const int n = g->n, m = g->m;
+    const long long S = (long long)g->max_dc * m;
+    if (S > 65535 || n > 65535 || d->n_beta > 65535 || d->n_alpha > 65535 || d->n_oms_alpha > 65535) return LDPC_OK;
+    if (resident_lds_bytes(n, (int)S, 1) > kLdsBytes) return LDPC_OK;
+
+    std::vector<int> perm_c(m), perm_v(n), pos_c(m), pos_v(n);
+    for (int i = 0; i < m; ++i) perm_c[i] = i;
+    for (int j = 0; j < n; ++j) perm_v[j] = j;
+    auto dc_of = [&](int i) { return g->h_check_ptr[i + 1] - g->h_check_ptr[i]; };
+    auto dv_of = [&](int j) { return g->h_var_ptr[j + 1] - g->h_var_ptr[j]; };
+    std::stable_sort(perm_c.begin(), perm_c.end(), [&](int a, int b) { return dc_of(a) > dc_of(b); });
+    std::stable_sort(perm_v.begin(), perm_v.end(), [&](int a, int b) { return dv_of(a) > dv_of(b); });
+    for (int p = 0; p < m; ++p) pos_c[perm_c[p]] = p;
+    for (int q = 0; q < n; ++q) pos_v[perm_v[q]] = q;
+
+    std::vector<uint8_t> dc_s(m), dv_s(n);
+    std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0);
+    std::vector<uint16_t> vslot((size_t)std::max(g->max_dv, 1) * n, 0), aslot(n), inv(n);
+    std::vector<int> slot_of_edge(g->E);
+    bool per_check = true;
+    for (int p = 0; p < m; ++p) {
+        const int i = perm_c[p], e0 = g->h_check_ptr[i], dc = dc_of(i);
+        dc_s[p] = (uint8_t)dc;
+        for (int t = 0; t < dc; ++t) {
+            const int e = e0 + t, slot = t * m + p;
+            slot_of_edge[e] = slot;
+            cvar[slot] = (uint16_t)pos_v[g->h_var_idx[e]];
+            bslot[slot] = (uint16_t)desc->beta_slot[e];
+            if (desc->beta_slot[e] != desc->beta_slot[e0]) per_check = false;
+            if (d->form == LDPC_C2V_OMS && desc->oms_alpha) oaslot[slot] = (uint16_t)desc->oms_alpha_slot[e];
+        }
+        bslot_c[p] = dc ? (uint16_t)desc->beta_slot[e0] : 0;
+    }
+    for (int q = 0; q < n; ++q) {
+        const int j = perm_v[q], s0 = g->h_var_ptr[j], dv = dv_of(j);
+        dv_s[q] = (uint8_t)dv;
+        aslot[q] = (uint16_t)desc->alpha_slot[j];
+        inv[j] = (uint16_t)q;
+        for (int k = 0; k < dv; ++k) vslot[(size_t)k * n + q] = (uint16_t)slot_of_edge[g->h_csc[s0 + k]];
+    }
+    ResidentPlan &pl = d->res;
+    pl = ResidentPlan{};
+    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv;
+    int rc = plan_upload(d, &pl.dc_s, dc_s);
+    if (!rc) rc = plan_upload(d, &pl.cvar, cvar);
+    if (!rc) rc = plan_upload(d, &pl.bslot, bslot);
+    if (!rc && per_check) rc = plan_upload(d, &pl.bslot_c, bslot_c);
+    if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha) rc = plan_upload(d, &pl.oaslot, oaslot);
+    if (!rc) rc = plan_upload(d, &pl.dv_s, dv_s);
+    if (!rc) rc = plan_upload(d, &pl.vslot, vslot);
+    if (!rc) rc = plan_upload(d, &pl.aslot, aslot);
+    if (!rc) rc = plan_upload(d, &pl.inv_perm_v, inv);
+    if (rc) return rc;
+
+    // geometry: G codewords per workgroup, NT threads.  Two 512-thread workgroups per CU (G = 2,
+    // ds_read/write_b64) let one workgroup's barrier wait overlap the other's phase; fall back to a
+    // single workgroup (G = 2 or 1) for larger codes.  LDPC_RESIDENT_G / _NT override for tuning.
+    int G = 0, NT = 0;
+    const char *eg = getenv("LDPC_RESIDENT_G"), *en = getenv("LDPC_RESIDENT_NT");
+    if (eg) G = atoi(eg);
+    if (en) NT = atoi(en);
+    if (G != 1 && G != 2 && G != 4) {
+        if (2 * resident_lds_bytes(n, (int)S, 2) <= kLdsBytes) G = 2;
+        else if (resident_lds_bytes(n, (int)S, 2) <= kLdsBytes) G = 2;
+        else G = 1;
+    }
+    if (resident_lds_bytes(n, (int)S, G) > kLdsBytes) G = resident_lds_bytes(n, (int)S, 2) <= kLdsBytes ? 2 : 1;
+    if (NT < 64 || NT > 1024 || NT % 64) {
+        const size_t per = resident_lds_bytes(n, (int)S, G);
+        const int blocks = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBytes / per));
+        NT = std::max(64, std::min(1024, (2048 / blocks) / 64 * 64));   // fill the CU's 2048 thread slots... 
+        NT = std::min(NT, 1024);
+        if (blocks >= 2) NT = std::min(NT, 512);
+    }
+    d->res_G = G; d->res_NT = NT; d->res_lds = resident_lds_bytes(n, (int)S, G);
+    d->res_ok = true;
+    return LDPC_OK;
+}
+
+template <int G>
+int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
+    const size_t lds = d->res_lds;
+#define LDPC_RES(FORM)                                                                                   \
+    do {                                                                                                 \
+        auto kfn = resident_decode<G, FORM>;                                                             \
+        HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
+    } while (0)
+    if (d->form == LDPC_C2V_NMS) LDPC_RES(FORM_NMS);
+    else if (d->form == LDPC_C2V_OMS) LDPC_RES(FORM_OMS);
+    else LDPC_RES(FORM_RCQ);
+#undef LDPC_RES
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+bool use_resident(const ldpc_decoder *d) { return d->res_ok && d->mode != LDPC_MODE_STREAM; }
+
 }  // namespace
 
 // =========================================================================================== C ABI
@@ -320,6 +453,10 @@ int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const i
     ldpc_graph *g = new (std::nothrow) ldpc_graph();
     if (!g) return fail(LDPC_ERR_ARG, "out of host memory");
     g->n = n; g->m = m; g->E = E; g->max_dc = max_dc; g->max_dv = max_dv;
+    g->h_check_ptr.assign(check_ptr, check_ptr + m + 1);
+    g->h_var_idx.assign(var_idx, var_idx + E);
+    g->h_var_ptr = var_ptr;
+    g->h_csc.assign(csc.begin(), csc.begin() + E);
     if (hipGetDevice(&g->device) != hipSuccess) {
         delete g;
         return fail(LDPC_ERR_HIP, "no HIP device available");
@@ -428,11 +565,33 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
         rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
         if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
     }
+    if (!rc) rc = build_resident_plan(d, desc);
     if (rc) {
         ldpc_decoder_destroy(d);
         return rc;
     }
     *out = d;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
+    if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_RESIDENT) return fail(LDPC_ERR_ARG, "bad mode");
+    if (mode == LDPC_MODE_RESIDENT && !d->res_ok)
+        return fail(LDPC_ERR_UNSUPPORTED, "code does not qualify for the LDS-resident engine "
+                                          "(fp32, dc <= 32, dv <= 8, state within 160 KiB of LDS)");
+    d->mode = mode;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4])
+{
+    if (!d || !out4) return fail(LDPC_ERR_ARG, "NULL argument");
+    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : LDPC_MODE_STREAM;
+    out4[1] = d->res_ok ? d->res_G : 0;
+    out4[2] = d->res_ok ? d->res_NT : 0;
+    out4[3] = d->res_ok ? (int32_t)d->res_lds : 0;
     return LDPC_OK;
 }
 
@@ -460,12 +619,14 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipFree(d->beta); (void)hipFree(d->alpha); (void)hipFree(d->oms_alpha);
     (void)hipFree(d->beta_slot); (void)hipFree(d->alpha_slot); (void)hipFree(d->oms_alpha_slot);
     (void)hipFree(d->thresholds); (void)hipFree(d->lut); (void)hipFree(d->q_of_iter_dev);
+    for (void *p : d->res_bufs) (void)hipFree(p);
     delete d;
 }
 
 size_t ldpc_decoder_workspace_bytes(const ldpc_decoder *d, int64_t batch)
 {
     if (!d || batch < 0) return 0;
+    if (use_resident(d)) return kAlign;               // the resident engine keeps its state in LDS
     return carve(d, batch, nullptr).total;
 }
 
@@ -479,6 +640,23 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
     if (!llr || !workspace) return fail(LDPC_ERR_ARG, "NULL llr/workspace");
     if (d->g->n == 0) return LDPC_OK;
     if (((uintptr_t)workspace % kAlign) != 0) return fail(LDPC_ERR_ARG, "workspace must be %zu-byte aligned", kAlign);
+    if (use_resident(d)) {
+        DeviceGuard guard(d->g->device);
+        ResidentArgs a{};
+        a.llr = (const float *)llr; a.batch = batch; a.T = d->T; a.early_stop = early_stop != 0;
+        a.beta = (const float *)d->beta; a.n_beta = d->n_beta;
+        a.alpha = (const float *)d->alpha; a.n_alpha = d->n_alpha;
+        a.oms_alpha = (const float *)d->oms_alpha; a.n_oms_alpha = d->n_oms_alpha;
+        a.thr = d->thresholds; a.n_levels = d->n_levels; a.q_of_iter = d->q_of_iter_dev;
+        a.bits = bits; a.posterior = (float *)posterior; a.iterations = iterations; a.success = success;
+        a.packed = packed_bits;
+        hipStream_t rs = (hipStream_t)stream;
+        switch (d->res_G) {
+        case 1: return launch_resident<1>(d, a, rs);
+        case 2: return launch_resident<2>(d, a, rs);
+        default: return launch_resident<4>(d, a, rs);
+        }
+    }
     const Workspace w = carve(d, batch, workspace);
     if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
     if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -492,6 +670,7 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])
 {
     if (!d || !out8 || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
+    if (use_resident(d)) return fail(LDPC_ERR_ARG, "workspace layout exists only in LDPC_MODE_STREAM");
     char *base = reinterpret_cast<char *>(kAlign);   // any non-null base: only differences are used
     const Workspace w = carve(d, batch, base);
     out8[0] = w.vec; out8[1] = w.tiles;
@@ -505,6 +684,7 @@ int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_
 {
     if (!d || !workspace || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
     if (iter < 0 || iter >= d->T) return fail(LDPC_ERR_ARG, "iter outside [0, T)");
+    if (use_resident(d)) return fail(LDPC_ERR_ARG, "debug sweeps need LDPC_MODE_STREAM");
     const Workspace w = carve(d, batch, workspace);
     if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace too small");
     DeviceGuard guard(d->g->device);

@@ -13,6 +13,7 @@ flatten their reference-style parameters into the tables this class uploads.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from dataclasses import dataclass
 from typing import Optional
@@ -132,7 +133,7 @@ class DecodeEngine:
             nat.check(lib.ldpc_decoder_create(C.byref(self.handle), self._ng.handle, C.byref(desc)),
                       "ldpc_decoder_create")
         self._ws: Optional[torch.Tensor] = None
-        self._pending_host = None   # host arrays of an in-flight async weight upload
+        self.set_mode(os.environ.get("LDPC_ENGINE_MODE", "auto"))
 
     def __del__(self):
         try:
@@ -141,6 +142,22 @@ class DecodeEngine:
                 self.handle = C.c_void_p()
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ engine choice
+    _MODES = {"auto": nat.MODE_AUTO, "stream": nat.MODE_STREAM, "resident": nat.MODE_RESIDENT}
+
+    def set_mode(self, mode: str):
+        """'auto' (LDS-resident fused kernel when the code qualifies, else streaming sweeps),
+        'stream', 'resident' -- both engines give identical results."""
+        nat.check(self._lib.ldpc_decoder_set_mode(self.handle, self._MODES[mode]), "ldpc_decoder_set_mode")
+        self._ws = None
+        return self
+
+    def info(self) -> dict:
+        out = np.zeros(4, dtype=np.int32)
+        nat.check(self._lib.ldpc_decoder_info(self.handle, nat.ptr(out)), "ldpc_decoder_info")
+        return {"engine": {1: "stream", 2: "resident"}[int(out[0])], "codewords_per_workgroup": int(out[1]),
+                "threads_per_workgroup": int(out[2]), "lds_bytes": int(out[3])}
 
     # ------------------------------------------------------------------ weights
     def set_weights(self, beta: Optional[np.ndarray], alpha: Optional[np.ndarray],

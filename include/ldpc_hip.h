@@ -94,6 +94,17 @@ typedef struct {
 } ldpc_decoder_desc;
 
 int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc);
+
+/* Two engines implement the same arithmetic (bit-identical results):
+ *   STREAM   : one kernel per sweep, messages in HBM ([tile][edge][W]); any code, fp32/fp64
+ *   RESIDENT : one fused kernel, messages in LDS for all T iterations; fp32 codes with
+ *              dc <= 32, dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code)
+ * AUTO (default) takes RESIDENT when the code qualifies. */
+enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2 };
+int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode);
+/* out4 = { engine a decode would use now (LDPC_MODE_*), codewords per workgroup, threads per
+ * workgroup, LDS bytes per workgroup } -- the last three 0 when the code does not qualify */
+int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4]);
 /* re-upload beta/alpha(/oms_alpha) tables of an existing decoder (same shapes);
  * enqueued on `stream`, host arrays must stay valid until it has run. */
 int ldpc_decoder_set_weights(ldpc_decoder *d, const void *beta, const void *alpha,

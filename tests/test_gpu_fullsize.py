@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
 
 
+@pytest.fixture(autouse=True, params=["auto", "stream"])
+def engine_mode(request, monkeypatch):
+    """both engines: 'auto' = LDS-resident fused kernel where the code qualifies, 'stream' = HBM sweeps"""
+    monkeypatch.setenv("LDPC_ENGINE_MODE", request.param)
+    return request.param
+
+
 def awgn_gpu(B, n, snr_db, seed, dev):
     s2 = 10.0 ** (-snr_db / 10.0)
     gen = torch.Generator(device=dev)

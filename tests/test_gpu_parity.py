@@ -19,6 +19,21 @@ QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
 POST_TOL = 1e-5
 
 
+@pytest.fixture(autouse=True, params=["auto", "stream"])
+def engine_mode(request, monkeypatch):
+    """every test runs on both engines: 'auto' picks the LDS-resident fused kernel for codes that
+    qualify (all the fp32 fixtures here), 'stream' forces the per-sweep HBM kernels"""
+    monkeypatch.setenv("LDPC_ENGINE_MODE", request.param)
+    return request.param
+
+
+def codes_of(engine, batch):
+    """per-edge quantiser codes are observable only in the streaming engine's HBM state"""
+    if engine.info()["engine"] != "stream":
+        return None
+    return engine.debug_c2v(batch).cpu().numpy()
+
+
 # --------------------------------------------------------------------------------- helpers
 def make_code(gold, max_iterations):
     from ldpc_decoder import LDPCCode
@@ -149,8 +164,9 @@ def check_rcq(code, sub, gpu, bc=3, qp=QP):
     np.testing.assert_array_equal(succ.cpu().numpy(), sub["success"])
     np.testing.assert_array_equal(bits.cpu().numpy(), sub["bits"].astype(np.int32))
     # per-edge quantiser codes (CSR order) of every codeword's last executed iteration
-    codes = dec._engine.debug_c2v(len(llr)).cpu().numpy()
-    np.testing.assert_array_equal(codes, final_codes(sub["codes"], sub["iters"]))
+    codes = codes_of(dec._engine, len(llr))
+    if codes is not None:
+        np.testing.assert_array_equal(codes, final_codes(sub["codes"], sub["iters"]))
     b1, s1, i1 = dec.decode(llr[1])
     assert isinstance(s1, bool) and isinstance(i1, int) and b1.dtype == torch.int32 and b1.device.type == "cpu"
     assert (s1, i1) == (bool(sub["success"][1]), int(sub["iters"][1]))
@@ -164,8 +180,9 @@ def check_wrcq(code, sub, gpu, wtype, bc=3, qp=QP):
     load_weights(dec, sub)
     check_neural(dec, sub, gpu)
     dec(torch.from_numpy(sub["llr"]).to(gpu))
-    codes = dec._engine.debug_c2v(len(sub["llr"])).cpu().numpy()
-    np.testing.assert_array_equal(codes, final_codes(sub["codes"], sub["iters"]))
+    codes = codes_of(dec._engine, len(sub["llr"]))
+    if codes is not None:
+        np.testing.assert_array_equal(codes, final_codes(sub["codes"], sub["iters"]))
     # RCQ posteriors are sums of a handful of table values: must be equal as values
     b, p, i = dec(torch.from_numpy(sub["llr"]).to(gpu))
     np.testing.assert_array_equal(p.cpu().numpy(), sub["posterior"])
@@ -277,7 +294,8 @@ def test_ira_batch_vs_oracle_all_decoders(early_stop, gpu_device, oracle_mod):
     np.testing.assert_array_equal(iters.cpu().numpy(), oi)
     np.testing.assert_array_equal(succ.cpu().numpy(), os_)
     np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-    np.testing.assert_array_equal(dec._engine.debug_c2v(B).cpu().numpy(), final_codes(oc, oi))
+    if codes_of(dec._engine, B) is not None:
+        np.testing.assert_array_equal(codes_of(dec._engine, B), final_codes(oc, oi))
 
     dec = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=2, max_iterations=10)
     beta, alpha = rand_weights(dec, rng)
@@ -286,7 +304,8 @@ def test_ira_batch_vs_oracle_all_decoders(early_stop, gpu_device, oracle_mod):
     np.testing.assert_array_equal(iters.cpu().numpy(), oi)
     np.testing.assert_array_equal(bits.cpu().numpy(), ob)
     np.testing.assert_array_equal(post.cpu().numpy(), op)
-    np.testing.assert_array_equal(dec._engine.debug_c2v(B).cpu().numpy(), final_codes(oc, oi))
+    if codes_of(dec._engine, B) is not None:
+        np.testing.assert_array_equal(codes_of(dec._engine, B), final_codes(oc, oi))
 
 
 def test_offset_minsum_vs_oracle(gpu_device, oracle_mod):

@@ -30,7 +30,12 @@ def main():
     for _ in range(5):
         eng.decode(llr, early_stop=False, want_posterior=False)
     e1.record(); e1.synchronize()
-    out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5}
+    out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5,
+           "engine": eng.info()}
+    out["Mcw_s"] = B / out["decode_ms"] / 1e3
+    if eng.info()["engine"] != "stream":
+        print(json.dumps(out))
+        return
     for which, name in ((0, "cn_ms"), (1, "vn_ms")):
         for _ in range(3):
             eng.debug_sweep(B, which, 1)
