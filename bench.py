@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-bench.py -- decoded codewords/s at fixed iterations + HBM roofline of the CN->VN sweep.
+bench.py -- decoded codewords/s at fixed iterations + HBM roofline of the dominant kernel.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload basic|neural2d|rcq|wrcq_dvbs2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -13,9 +13,15 @@ fp32, 10 iterations, batch 65536 per GPU, SNR 2.0 dB, fixed iterations (early_st
 N > 1: weak scaling, every rank decodes its own 65536 codewords and the step ends with the
 RCCL all-gather of the bit-packed hard decisions; value = all ranks' codewords / max-rank time.
 
+Two engines implement the path (identical results): the LDS-resident fused kernel (codes whose
+state fits LDS, e.g. the (1998,1512) code) and the HBM-streaming sweep kernels (any code).  The
+step uses whichever the library picks (config.engine); with the resident engine the streaming
+engine is measured too and reported under "stream_engine".
+
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline     : the check-node sweep kernel timed live with HIP events on its stream,
-                 ALGORITHMIC bytes (8E per codeword fp32, 5E RCQ) / time vs 8 TB/s
+  roofline     : the dominant kernel timed live with HIP events on its stream; ALGORITHMIC bytes
+                 of SURVEY 8d (CN sweep: 8E per codeword fp32, 5E RCQ; whole decode:
+                 T(16E+4n)+8n) / time vs 8 TB/s
   cpu_baseline : the CPU oracle (C port of the reference loops) on a bounded sample
 """
 import argparse
@@ -138,6 +144,7 @@ def main():
     ap.add_argument("--early-stop", action="store_true", help="reference early-exit semantics instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,40 +218,87 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the check-node (CN->VN) sweep, timed live with HIP
-        # events on the stream it is launched on (torch's current stream).
-        reps = max(args.sweep_reps, 1)
+        out["config"]["engine"] = eng.info()
         rcq_like = args.workload in ("rcq", "wrcq_dvbs2")
-        bytes_cn = (5 if rcq_like else 8) * g.E * B            # read v2c 4E + write c2v 4E (1E as codes)
+        per_cw_decode = T * ((10 if rcq_like else 16) * g.E + 4 * g.n) + 8 * g.n     # SURVEY 8d, whole decode
+        bytes_cn = (5 if rcq_like else 8) * g.E * B            # CN sweep: read v2c 4E + write c2v 4E (1E as codes)
         bytes_vn = ((5 if rcq_like else 8) * g.E + 4 * g.n) * B
-        times = {}
-        for which, name in ((0, "cn_sweep"), (1, "vn_sweep")):
-            for _ in range(3):
-                eng.debug_sweep(B, which, 1)
+        reps = max(args.sweep_reps, 1)
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic_db = {}
+        if os.path.exists(tf):
+            try:
+                traffic_db = json.load(open(tf)).get(args.workload, {})
+            except Exception:
+                traffic_db = {}
+
+        def time_sweeps(engine):
+            """CN / VN sweep kernels of the streaming engine, timed live with HIP events on the stream
+            they are launched on (torch's current stream)"""
+            engine.decode(llr, early_stop=False, want_posterior=False)          # leaves valid state in the workspace
+            times = {}
+            for which, name in ((0, "cn_sweep"), (1, "vn_sweep")):
+                for _ in range(3):
+                    engine.debug_sweep(B, which, 1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    engine.debug_sweep(B, which, 1)
+                e1.record()
+                e1.synchronize()
+                times[name] = e0.elapsed_time(e1) / reps                        # ms per launch
+            return times
+
+        def stream_roofline(engine):
+            times = time_sweeps(engine)
+            ach = bytes_cn / (times["cn_sweep"] * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep, streaming engine)",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic_db.get("cn_sweep_bytes_per_launch"),
+                    "algorithmic_bytes_per_launch": bytes_cn, "ms_per_launch": times["cn_sweep"],
+                    "vn_sweep": {"ms_per_launch": times["vn_sweep"],
+                                 "achieved": bytes_vn / (times["vn_sweep"] * 1e-3) / 1e9,
+                                 "algorithmic_bytes_per_launch": bytes_vn}}
+
+        if eng.info()["engine"] == "resident":
+            # dominant kernel = ldpc::resident_decode (the whole decode is this one launch): time it with
+            # HIP events; ALGORITHMIC bytes are those of the reference formulation (SURVEY 8d), which this
+            # kernel does not move -- messages stay in LDS -- hence frac can exceed 1 and `traffic` << them.
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                eng.debug_sweep(B, which, 1)
+                eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
             e1.record()
             e1.synchronize()
-            times[name] = e0.elapsed_time(e1) / reps            # ms per launch
-        achieved = bytes_cn / (times["cn_sweep"] * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get("cn_sweep_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep)",
-                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes_per_launch": bytes_cn, "ms_per_launch": times["cn_sweep"],
-                           "vn_sweep": {"ms_per_launch": times["vn_sweep"],
-                                        "achieved": bytes_vn / (times["vn_sweep"] * 1e-3) / 1e9,
-                                        "algorithmic_bytes_per_launch": bytes_vn}}
-        per_decode = (T * ((10 if rcq_like else 16) * g.E + 4 * g.n) + 8 * g.n) * B
-        out["decode_algorithmic_GBps"] = per_decode / (ms_per_step * 1e-3) / 1e9
+            ms = e0.elapsed_time(e1) / reps
+            ach = per_cw_decode * B / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "ldpc::resident_decode (fused T-iteration decode, messages resident in LDS)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic_db.get("resident_decode_bytes_per_launch"),
+                               "algorithmic_bytes_per_launch": per_cw_decode * B, "ms_per_launch": ms,
+                               "note": "algorithmic bytes = T(16E+4n)+8n per codeword (10E for RCQ) of the HBM-streaming "
+                                       "formulation; the fused kernel keeps messages in LDS, so frac > 1 means it beats "
+                                       "the HBM roofline of that formulation; its own limiter is LDS/instruction issue"}
+            if not args.no_stream_leg:
+                # the HBM-bound engine (used for codes that do not fit LDS), same workload, for the record
+                os.environ["LDPC_ENGINE_MODE"] = "stream"
+                try:
+                    eng_s, dec_s, _ = build_decoder(args.workload, device)
+                finally:
+                    os.environ.pop("LDPC_ENGINE_MODE", None)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                eng_s.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
+                e0.record()
+                for _ in range(3):
+                    eng_s.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
+                e1.record()
+                e1.synchronize()
+                out["stream_engine"] = {"ms_per_step": e0.elapsed_time(e1) / 3,
+                                        "value": B / (e0.elapsed_time(e1) / 3 * 1e-3), "roofline": stream_roofline(eng_s)}
+                del eng_s, dec_s
+        else:
+            out["roofline"] = stream_roofline(eng)
+        out["decode_algorithmic_GBps"] = per_cw_decode * B / (ms_per_step * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)
         print(json.dumps(out))

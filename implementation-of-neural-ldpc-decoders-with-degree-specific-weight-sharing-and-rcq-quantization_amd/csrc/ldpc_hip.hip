@@ -290,9 +290,7 @@ int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool 
 
 
 // ---- LDS-resident engine: plan (host) ---------------------------------------------------------
-constexpr size_t kLdsBytes = 160 * 1024 - 512;    // 160 KiB per CU minus static/alignment slack
-
-size_t resident_lds_bytes(int n, int S, int G) { return ((size_t)S + n) * G * sizeof(float) + (size_t)n + 16; }
+constexpr size_t kLdsBytes = 160 * 1024;          // LDS per CU; one workgroup may take all of it
 
 template <typename X>
 int plan_upload(ldpc_decoder *d, const X **dst, const std::vector<X> &src)
@@ -305,6 +303,19 @@ int plan_upload(ldpc_decoder *d, const X **dst, const std::vector<X> &src)
     return LDPC_OK;
 }
 
+int resident_alpha_floats(const ldpc_decoder *d)
+{
+    const long long cnt = (long long)d->T * d->n_alpha;
+    return cnt <= kResAlphaMax ? (int)cnt : 0;
+}
+
+// G codewords per workgroup fit when the state is within LDS and slot byte offsets fit 16 bits
+bool resident_fits(const ldpc_decoder *d, long long S, int G, int blocks)
+{
+    if (S * G * 4 > 65535) return false;
+    return blocks * res_lds_total((int)S, d->g->n, G, resident_alpha_floats(d)) <= kLdsBytes;
+}
+
 // Sort checks and variables by degree (stable, descending), lay the edges out ELL-transposed.
 int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
 {
@@ -313,8 +324,21 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     if (d->dtype != LDPC_F32 || g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
     const int n = g->n, m = g->m;
     const long long S = (long long)g->max_dc * m;
-    if (S > 65535 || n > 65535 || d->n_beta > 65535 || d->n_alpha > 65535 || d->n_oms_alpha > 65535) return LDPC_OK;
-    if (resident_lds_bytes(n, (int)S, 1) > kLdsBytes) return LDPC_OK;
+    if (S > 65535 || n > 65535 || d->n_beta > 65535 || d->n_alpha >= (1 << 24) || d->n_oms_alpha > 65535) return LDPC_OK;
+    if (!resident_fits(d, S, 1, 1)) return LDPC_OK;
+
+    // geometry: G codewords per workgroup, NT threads.  Two 512-thread workgroups per CU (G = 2,
+    // ds_read/write_b64) let one workgroup's barrier wait overlap the other's phase -- measured best on
+    // the (1998,1512) code; larger codes fall back to one workgroup per CU.  LDPC_RESIDENT_G / _NT
+    // override for tuning.
+    int G = 0, NT = 0;
+    const char *eg = getenv("LDPC_RESIDENT_G"), *en = getenv("LDPC_RESIDENT_NT");
+    if (eg) G = atoi(eg);
+    if (en) NT = atoi(en);
+    if (!((G == 1 || G == 2 || G == 4) && resident_fits(d, S, G, 1))) G = resident_fits(d, S, 2, 1) ? 2 : 1;
+    int blocks = 1;
+    while (blocks < 8 && resident_fits(d, S, G, blocks + 1)) ++blocks;
+    if (NT < 64 || NT > 1024 || NT % 64) NT = blocks >= 2 ? 512 : 1024;
 
     std::vector<int> perm_c(m), perm_v(n), pos_c(m), pos_v(n);
     for (int i = 0; i < m; ++i) perm_c[i] = i;
@@ -326,9 +350,10 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     for (int p = 0; p < m; ++p) pos_c[perm_c[p]] = p;
     for (int q = 0; q < n; ++q) pos_v[perm_v[q]] = q;
 
-    std::vector<uint8_t> dc_s(m), dv_s(n);
-    std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0);
-    std::vector<uint16_t> vslot((size_t)std::max(g->max_dv, 1) * n, 0), aslot(n), inv(n);
+    std::vector<uint8_t> dc_s(m);
+    std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0), inv(n);
+    std::vector<uint32_t> vmeta(n);
+    std::vector<uint4> vslot8(n);
     std::vector<int> slot_of_edge(g->E);
     bool per_check = true;
     for (int p = 0; p < m; ++p) {
@@ -346,10 +371,11 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     }
     for (int q = 0; q < n; ++q) {
         const int j = perm_v[q], s0 = g->h_var_ptr[j], dv = dv_of(j);
-        dv_s[q] = (uint8_t)dv;
-        aslot[q] = (uint16_t)desc->alpha_slot[j];
+        vmeta[q] = (uint32_t)dv | ((uint32_t)desc->alpha_slot[j] << 8);
         inv[j] = (uint16_t)q;
-        for (int k = 0; k < dv; ++k) vslot[(size_t)k * n + q] = (uint16_t)slot_of_edge[g->h_csc[s0 + k]];
+        uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < dv; ++k) off[k] = (uint32_t)slot_of_edge[g->h_csc[s0 + k]] * G * 4;
+        vslot8[q] = make_uint4(off[0] | off[1] << 16, off[2] | off[3] << 16, off[4] | off[5] << 16, off[6] | off[7] << 16);
     }
     ResidentPlan &pl = d->res;
     pl = ResidentPlan{};
@@ -359,33 +385,12 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     if (!rc) rc = plan_upload(d, &pl.bslot, bslot);
     if (!rc && per_check) rc = plan_upload(d, &pl.bslot_c, bslot_c);
     if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha) rc = plan_upload(d, &pl.oaslot, oaslot);
-    if (!rc) rc = plan_upload(d, &pl.dv_s, dv_s);
-    if (!rc) rc = plan_upload(d, &pl.vslot, vslot);
-    if (!rc) rc = plan_upload(d, &pl.aslot, aslot);
+    if (!rc) rc = plan_upload(d, &pl.vmeta, vmeta);
+    if (!rc) rc = plan_upload(d, &pl.vslot8, vslot8);
     if (!rc) rc = plan_upload(d, &pl.inv_perm_v, inv);
     if (rc) return rc;
-
-    // geometry: G codewords per workgroup, NT threads.  Two 512-thread workgroups per CU (G = 2,
-    // ds_read/write_b64) let one workgroup's barrier wait overlap the other's phase; fall back to a
-    // single workgroup (G = 2 or 1) for larger codes.  LDPC_RESIDENT_G / _NT override for tuning.
-    int G = 0, NT = 0;
-    const char *eg = getenv("LDPC_RESIDENT_G"), *en = getenv("LDPC_RESIDENT_NT");
-    if (eg) G = atoi(eg);
-    if (en) NT = atoi(en);
-    if (G != 1 && G != 2 && G != 4) {
-        if (2 * resident_lds_bytes(n, (int)S, 2) <= kLdsBytes) G = 2;
-        else if (resident_lds_bytes(n, (int)S, 2) <= kLdsBytes) G = 2;
-        else G = 1;
-    }
-    if (resident_lds_bytes(n, (int)S, G) > kLdsBytes) G = resident_lds_bytes(n, (int)S, 2) <= kLdsBytes ? 2 : 1;
-    if (NT < 64 || NT > 1024 || NT % 64) {
-        const size_t per = resident_lds_bytes(n, (int)S, G);
-        const int blocks = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBytes / per));
-        NT = std::max(64, std::min(1024, (2048 / blocks) / 64 * 64));   // fill the CU's 2048 thread slots... 
-        NT = std::min(NT, 1024);
-        if (blocks >= 2) NT = std::min(NT, 512);
-    }
-    d->res_G = G; d->res_NT = NT; d->res_lds = resident_lds_bytes(n, (int)S, G);
+    d->res_G = G; d->res_NT = NT;
+    d->res_lds = res_lds_total((int)S, n, G, resident_alpha_floats(d));
     d->res_ok = true;
     return LDPC_OK;
 }
@@ -397,7 +402,7 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
     const size_t lds = d->res_lds;
 #define LDPC_RES(FORM)                                                                                   \
     do {                                                                                                 \
-        auto kfn = resident_decode<G, FORM>;                                                             \
+        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true> : resident_decode<G, FORM, false>;    \
         HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
     } while (0)
@@ -650,6 +655,8 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
         a.thr = d->thresholds; a.n_levels = d->n_levels; a.q_of_iter = d->q_of_iter_dev;
         a.bits = bits; a.posterior = (float *)posterior; a.iterations = iterations; a.success = success;
         a.packed = packed_bits;
+        { const char *dbg = getenv("LDPC_RES_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
+        a.alpha_in_lds = resident_alpha_floats(d) > 0;
         hipStream_t rs = (hipStream_t)stream;
         switch (d->res_G) {
         case 1: return launch_resident<1>(d, a, rs);

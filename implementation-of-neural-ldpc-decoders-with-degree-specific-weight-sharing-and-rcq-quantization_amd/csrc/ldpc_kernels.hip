@@ -276,40 +276,38 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
 template <int N, int SKIP, int ORDER, typename T, int DV>
 __device__ __forceinline__ T sum_ct(const T (&x)[DV])
 {
+    // The additions of the reference's zero-initialised accumulators ("0 + x", "+ 0") are left out:
+    // they change nothing but the sign of an exact zero, which no later operation can observe as a
+    // value (|.|, comparisons, the sign-parity of a zero-magnitude message, quantize(+-0) = 0).
 #define LDPC_AT(u) x[((SKIP) >= 0 && (u) >= (SKIP)) ? (u) + 1 : (u)]
     if constexpr (N == 0) {
         return (T)0;
     } else if constexpr (ORDER == 0) {
-        if constexpr (N < 8) {
-            T p[4] = {(T)0, (T)0, (T)0, (T)0};
-            constexpr int G = N / 4;
+        if constexpr (N < 4) {
+            T p0 = LDPC_AT(0);
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
+            for (int u = 1; u < N; ++u) p0 = p0 + LDPC_AT(u);
+            return p0;
+        } else if constexpr (N < 8) {
+            T p0 = LDPC_AT(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[k] = p[k] + LDPC_AT(4 * r + k);
-            }
-#pragma unroll
-            for (int u = 4 * G; u < N; ++u) p[0] = p[0] + LDPC_AT(u);
-            p[0] = p[0] + p[1];
-            p[0] = p[0] + p[2];
-            p[0] = p[0] + p[3];
-            return p[0];
+            for (int u = 4; u < N; ++u) p0 = p0 + LDPC_AT(u);      // remainder joins partial 0 first
+            p0 = p0 + LDPC_AT(1);
+            p0 = p0 + LDPC_AT(2);
+            p0 = p0 + LDPC_AT(3);
+            return p0;
         } else {
             static_assert(N == 8, "compile-time torch order only up to 8 operands");
-            T fin = (T)0;
+            T fin = LDPC_AT(0);                                    // one 8-lane vector: lanes added in order
 #pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                T q = (T)0 + LDPC_AT(l);
-                q = q + (T)0; q = q + (T)0; q = q + (T)0;
-                fin = fin + q;
-            }
+            for (int l = 1; l < 8; ++l) fin = fin + LDPC_AT(l);
             return fin;
         }
     } else {
         if constexpr (N < 8) {
-            T res = (T)-0.0;
+            T res = LDPC_AT(0);
 #pragma unroll
-            for (int u = 0; u < N; ++u) res = res + LDPC_AT(u);
+            for (int u = 1; u < N; ++u) res = res + LDPC_AT(u);
             return res;
         } else {
             static_assert(N == 8, "compile-time numpy order only up to 8 operands");

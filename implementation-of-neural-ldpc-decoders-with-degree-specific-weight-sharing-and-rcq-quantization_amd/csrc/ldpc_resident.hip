@@ -5,16 +5,23 @@
 // Mapping (the transpose of the streaming kernels): lanes run over the NODES of the graph,
 // the G codewords of the workgroup ride along as a G-wide vector per lane (ds_read/write_b64
 // for G = 2, b128 for G = 4).
-//   msg  [S][G]  fp32   one slot per edge, "ELL-transposed" check-major: slot(p,t) = t*m + p
-//                       (p = position of the check after sorting by degree) -> consecutive
-//                       lanes hit consecutive LDS words in the check phase (conflict-free)
+//   msg  [S][G]  fp32   at LDS offset 0; one slot per edge, "ELL-transposed" check-major:
+//                       slot(p,t) = t*m + p  (p = position of the check after sorting by degree)
+//                       -> consecutive lanes hit consecutive LDS words in the check phase
 //   llr_s[n][G]  fp32   channel LLRs in degree-sorted variable order
 //   bits_s[n]    u8     hard decisions of the G codewords (bit g), for the syndrome
+//   alpha_s      fp32   the [T][n_alpha] V2C weight table (when it is small)
 // One array holds both message directions in place: the check phase turns v2c into c2v slot by
-// slot, the variable phase gathers its dv slots (index list vslot), forms the leave-one-out sums
-// in the reference's association order and scatters v2c back.  Nodes are sorted by degree so a
-// wave runs one compile-time body.  Arithmetic is the streaming kernels' (same helpers), so the
-// two engines are bit-identical (the GPU parity tests run every case on both).
+// slot, the variable phase gathers its dv slots (byte offsets, 8 x u16 in one 16-byte load), forms
+// the leave-one-out sums in the reference's association order and scatters v2c back.
+//
+// The engine is bound by instruction issue, not by LDS or HBM, so the phases are written for
+// instruction count: nodes are sorted by degree and every wave whose lanes share one degree (all
+// but the class-boundary waves) runs wave-uniform control flow -- scalar loop counters, one scalar
+// branch into the compile-time body of its degree; min1/min2 by v_med3; the sign product as an XOR
+// of raw bit patterns; index lists fetched one variable ahead.
+// Arithmetic is the streaming kernels' (same helpers), so the two engines give identical results
+// (the GPU parity tests run every case on both).
 //
 // Early stop (reference semantics): every iteration a posterior pass + syndrome pass finds the
 // codewords that just converged; their posterior is recomputed into their (now dead) LLR slots
@@ -33,9 +40,9 @@ struct ResidentPlan {
     const uint16_t *bslot_c;      // [m] or null: column shared by all edges of check p (Basic, RCQ,
                                   //              sharing types 2-4) -> one table read per check
     const uint16_t *oaslot;       // [max_dc*m]   OMS alpha column (or null)
-    const uint8_t *dv_s;          // [n]          degree of the variable at sorted position q
-    const uint16_t *vslot;        // [max_dv*n]   message slot of the k-th (ascending check) edge of q
-    const uint16_t *aslot;        // [n]          alpha table column of q
+    const uint32_t *vmeta;        // [n]          degree | alpha column << 8 of sorted variable q
+    const uint4 *vslot8;          // [n]          8 x u16: LDS byte offset of the k-th (ascending
+                                  //              check) edge's slot, = slot * G * 4
     const uint16_t *inv_perm_v;   // [n]          sorted position of original variable j
 };
 
@@ -48,90 +55,128 @@ struct ResidentArgs {
     const float *oms_alpha; int n_oms_alpha;
     const float *thr; int n_levels; const int *q_of_iter;
     int *bits; float *posterior; int *iterations; uint8_t *success; uint8_t *packed;
+    int alpha_in_lds;             // T * n_alpha floats staged in LDS
+    int debug_skip;               // timing experiments only (LDPC_RES_DEBUG): bit0 skip check phase, bit1 skip variable phase
 };
 
+constexpr int kResAlphaMax = 1024;   // floats of alpha table kept in LDS
+
+__device__ __forceinline__ bool wave_uniform(int v, int &vw)
+{
+    vw = __builtin_amdgcn_readfirstlane(v);
+    return __ballot(v != vw) == 0ull;
+}
+
 // ---- check phase: v2c -> c2v in place, lane = check -----------------------------------------
-template <int G, int FORM>
-__device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, float *__restrict__ msg,
+//   pass 1  per value: min1' = med3(a, min1, -inf) = min, min2' = med3(a, min1, min2), signs ^= bits(x)
+//   pass 2  re-reads the slot (LDS reads are cheap here): the arg-min edge is recognised by
+//           |x| == min1 -- on a tie min2 == min1, so which tied edge "is" the arg-min is
+//           value-irrelevant, exactly as with the reference's first-index argmin -- and the sign of
+//           the product of the OTHER signs is bit 31 of (signs ^ x).
+template <int G, int FORM, bool BPC, bool UNI>
+__device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned char *smem, int p, int dc, int dcw,
+                                               float b_check, const float *__restrict__ beta_row,
+                                               const float *__restrict__ oa_row, const float (&th)[8],
+                                               const float *__restrict__ thr, int n_levels)
+{
+    using P = Pack<float, G>;
+    constexpr int kEl = G * 4;
+    const int trip = UNI ? dcw : dc;
+    const unsigned stride = (unsigned)pl.m * kEl;
+    float m1[G], m2[G];
+    uint32_t sacc[G];
+    unsigned nz[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m1[g] = inf_of<float>(); m2[g] = inf_of<float>(); sacc[g] = 0; nz[g] = 0;
+    }
+    unsigned addr = (unsigned)p * kEl;
+#pragma unroll 4
+    for (int t = 0; t < trip; ++t) {
+        const P v = *reinterpret_cast<const P *>(smem + addr);
+        addr += stride;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float a = __builtin_fabsf(v.x[g]);
+            sacc[g] ^= __float_as_uint(v.x[g]);
+            if (FORM == FORM_OMS) nz[g] += (a == 0.0f) ? 1u : 0u;
+            m2[g] = __builtin_amdgcn_fmed3f(a, m1[g], m2[g]);
+            m1[g] = __builtin_amdgcn_fmed3f(a, m1[g], -inf_of<float>());   // = min(a, min1), no canonicalise ops
+        }
+    }
+    if (trip == 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) m2[g] = m1[g];     // "min2_val = min_val" for a degree-1 check
+    }
+    addr = (unsigned)p * kEl;
+    int slot = p;
+#pragma unroll 2
+    for (int t = 0; t < trip; ++t) {
+        const float b = BPC ? b_check : beta_row[pl.bslot[slot]];
+        float oa = 0.0f;
+        if (FORM == FORM_OMS && oa_row) oa = oa_row[pl.oaslot[slot]];
+        const P v = *reinterpret_cast<const P *>(smem + addr);
+        P o;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float a = __builtin_fabsf(v.x[g]);
+            const float raw = (a == m1[g]) ? m2[g] : m1[g];
+            const uint32_t sflip = (__float_as_uint(v.x[g]) ^ sacc[g]) & 0x80000000u;
+            if (FORM == FORM_NMS) {
+                o.x[g] = __uint_as_float(__float_as_uint(b * raw) ^ sflip);
+            } else if (FORM == FORM_OMS) {
+                const unsigned ownz = (a == 0.0f) ? 1u : 0u;
+                const bool nonzero = (nz[g] - ownz) == 0;
+                const float d = raw - b;
+                const float r = d > 0.0f ? d : 0.0f;
+                const float val = r - oa;
+                o.x[g] = nonzero ? __uint_as_float(__float_as_uint(val) ^ sflip) : 0.0f;
+            } else {
+                // quantise + reconstruct in one go: value = (1 - 2*sign_bit) * tau[level]
+                const float w = __uint_as_float(__float_as_uint(b * raw) ^ sflip);
+                const float mag = __builtin_fabsf(w);
+                float rec = (n_levels <= 8) ? th[0] : thr[0];          // level 0 when nothing matches
+                if (n_levels <= 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;
+                } else {
+                    for (int q = 0; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                }
+                o.x[g] = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
+            }
+        }
+        *reinterpret_cast<P *>(smem + addr) = o;
+        addr += stride;
+        slot += pl.m;
+    }
+}
+
+// `dc_pre` / `b_pre` are the first round's degree and per-check beta, fetched by the caller ahead of
+// the barrier so their global-memory latency is off the critical path.
+template <int G, int FORM, bool BPC>
+__device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned char *smem,
                                                 const float *__restrict__ beta_row,
                                                 const float *__restrict__ oa_row,
                                                 const float *__restrict__ thr, int n_levels,
-                                                int tid, int nt)
+                                                int dc_pre, float b_pre, int tid, int nt)
 {
-    using P = Pack<float, G>;
-    P *M = reinterpret_cast<P *>(msg);
     float th[8];
     if (FORM == FORM_RCQ) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
     }
+    int dc = dc_pre;
+    float b_check = b_pre;
     for (int p = tid; p < pl.m; p += nt) {
-        const int dc = pl.dc_s[p];
-        const float b_check = pl.bslot_c ? beta_row[pl.bslot_c[p]] : 0.0f;
-        float m1[G], m2[G];
-        int idx[G];
-        uint32_t sm[G], zm[G];
-        unsigned nz[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            m1[g] = inf_of<float>(); m2[g] = inf_of<float>(); idx[g] = 0; sm[g] = 0; zm[g] = 0; nz[g] = 0;
+        if (p != tid) {
+            dc = pl.dc_s[p];
+            b_check = BPC ? beta_row[pl.bslot_c[p]] : 0.0f;
         }
-        for (int t = 0; t < dc; ++t) {
-            const P v = M[t * pl.m + p];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float a = __builtin_fabsf(v.x[g]);
-                sm[g] |= signbit_of<float>(v.x[g]) << t;
-                if (FORM == FORM_OMS) {
-                    const unsigned z = (a == 0.0f) ? 1u : 0u;
-                    nz[g] += z;
-                    zm[g] |= z << t;
-                }
-                if (a < m1[g]) { m2[g] = m1[g]; m1[g] = a; idx[g] = t; }
-                else if (a < m2[g]) { m2[g] = a; }
-            }
-        }
-        unsigned par[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            par[g] = __popc(sm[g]) & 1u;
-            if (dc == 1) m2[g] = m1[g];
-        }
-        for (int t = 0; t < dc; ++t) {
-            const int slot = t * pl.m + p;
-            const float b = pl.bslot_c ? b_check : beta_row[pl.bslot[slot]];
-            float oa = 0.0f;
-            if (FORM == FORM_OMS && oa_row) oa = oa_row[pl.oaslot[slot]];
-            P o;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float raw = (t == idx[g]) ? m2[g] : m1[g];
-                const unsigned neg = par[g] ^ ((sm[g] >> t) & 1u);
-                if (FORM == FORM_NMS) {
-                    o.x[g] = flip_sign<float>(b * raw, neg);
-                } else if (FORM == FORM_OMS) {
-                    const unsigned ownz = (zm[g] >> t) & 1u;
-                    const bool nonzero = (nz[g] - ownz) == 0;
-                    const float d = raw - b;
-                    const float r = d > 0.0f ? d : 0.0f;
-                    const float val = r - oa;
-                    o.x[g] = nonzero ? flip_sign<float>(val, neg) : 0.0f;
-                } else {
-                    // quantise + reconstruct in one go: value = (1 - 2*sign_bit) * tau[level]
-                    const float w = flip_sign<float>(b * raw, neg);
-                    const float mag = __builtin_fabsf(w);
-                    float rec = (n_levels <= 8) ? th[0] : thr[0];          // level 0 when nothing matches
-                    if (n_levels <= 8) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;
-                    } else {
-                        for (int q = 0; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
-                    }
-                    o.x[g] = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
-                }
-            }
-            M[slot] = o;
-        }
+        int dcw;
+        if (wave_uniform(dc, dcw))
+            res_check_body<G, FORM, BPC, true>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
+        else
+            res_check_body<G, FORM, BPC, false>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
     }
 }
 
@@ -140,19 +185,17 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, float *_
 // MODE 1: posterior -> hard-decision byte bits_s[q]; components in `emask` also overwrite their
 //         (dead) LLR slot with the posterior so the output pass can read it in original order
 template <int G, int DV, int MODE>
-__device__ __forceinline__ void res_var_body(const ResidentPlan &pl, float *__restrict__ msg,
-                                             float *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
-                                             int q, float a, unsigned emask)
+__device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restrict__ llr_s,
+                                             uint8_t *__restrict__ bits_s, int q, const uint4 &s8,
+                                             float a, unsigned emask)
 {
     using P = Pack<float, G>;
-    P *M = reinterpret_cast<P *>(msg);
     P *L = reinterpret_cast<P *>(llr_s);
-    int slot[DV > 0 ? DV : 1];
+    const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,
+                             s8.z & 0xffffu, s8.z >> 16, s8.w & 0xffffu, s8.w >> 16};
     P x[DV > 0 ? DV : 1];
 #pragma unroll
-    for (int k = 0; k < DV; ++k) slot[k] = pl.vslot[k * pl.n + q];
-#pragma unroll
-    for (int k = 0; k < DV; ++k) x[k] = M[slot[k]];
+    for (int k = 0; k < DV; ++k) x[k] = *reinterpret_cast<const P *>(smem + off[k]);
     P l = L[q];
     if constexpr (MODE == 0) {
         P out[DV > 0 ? DV : 1];
@@ -171,7 +214,7 @@ __device__ __forceinline__ void res_var_body(const ResidentPlan &pl, float *__re
             if constexpr (DV >= 8) out[7].x[g] = l.x[g] + a * sum_ct<DV - 1, 7, 0, float>(xs);
         }
 #pragma unroll
-        for (int k = 0; k < DV; ++k) M[slot[k]] = out[k];
+        for (int k = 0; k < DV; ++k) *reinterpret_cast<P *>(smem + off[k]) = out[k];
     } else {
         unsigned byte = 0;
         bool store = false;
@@ -190,20 +233,46 @@ __device__ __forceinline__ void res_var_body(const ResidentPlan &pl, float *__re
 }
 
 template <int G, int MODE>
-__device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, float *__restrict__ msg,
+__device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__restrict__ llr_s,
+                                                 uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &s8,
+                                                 float a, unsigned emask)
+{
+#define LDPC_RV(D) case D: res_var_body<G, D, MODE>(smem, llr_s, bits_s, q, s8, a, emask); break;
+    switch (dv) {
+        LDPC_RV(0) LDPC_RV(1) LDPC_RV(2) LDPC_RV(3) LDPC_RV(4) LDPC_RV(5) LDPC_RV(6) LDPC_RV(7) LDPC_RV(8)
+    default: break;   // host admits only max_dv <= 8 to this engine
+    }
+#undef LDPC_RV
+}
+
+// Index data (degree, alpha column, the 8 slot offsets) of the NEXT variable of a lane is fetched
+// from global memory (L1/L2 resident, shared by every workgroup) while the current one is processed.
+template <int G, int MODE>
+__device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned char *smem,
                                               float *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
-                                              const float *__restrict__ alpha_row, unsigned emask,
+                                              const float *__restrict__ alpha_lds,
+                                              const float *__restrict__ alpha_glb, unsigned emask,
                                               int tid, int nt)
 {
-    for (int q = tid; q < pl.n; q += nt) {
-        const int dv = pl.dv_s[q];
-        const float a = (MODE == 0) ? alpha_row[pl.aslot[q]] : 0.0f;
-#define LDPC_RV(D) case D: res_var_body<G, D, MODE>(pl, msg, llr_s, bits_s, q, a, emask); break;
-        switch (dv) {
-            LDPC_RV(0) LDPC_RV(1) LDPC_RV(2) LDPC_RV(3) LDPC_RV(4) LDPC_RV(5) LDPC_RV(6) LDPC_RV(7) LDPC_RV(8)
-        default: break;   // host admits only max_dv <= 8 to this engine
-        }
-#undef LDPC_RV
+    const int n = pl.n;
+    int q = tid;
+    unsigned meta = 0;
+    uint4 s8 = make_uint4(0, 0, 0, 0);
+    if (q < n) { meta = pl.vmeta[q]; s8 = pl.vslot8[q]; }
+    while (q < n) {
+        const int qn = q + nt;
+        unsigned metan = 0;
+        uint4 s8n = make_uint4(0, 0, 0, 0);
+        if (qn < n) { metan = pl.vmeta[qn]; s8n = pl.vslot8[qn]; }
+        const int dv = (int)(meta & 0xffu);
+        float a = 0.0f;                                                  // LDS copy of the table when small
+        if (MODE == 0) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
+        int dvw;
+        if (wave_uniform(dv, dvw))
+            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, s8, a, emask);      // scalar branch
+        else
+            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dv, s8, a, emask);       // class-boundary wave
+        q = qn; meta = metan; s8 = s8n;
     }
 }
 
@@ -215,8 +284,14 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
     unsigned acc = 0;
     for (int p = tid; p < pl.m; p += nt) {
         const int dc = pl.dc_s[p];
+        int dcw;
         unsigned x = 0;
-        for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.m + p]];
+        if (wave_uniform(dc, dcw)) {
+#pragma unroll 8
+            for (int t = 0; t < dcw; ++t) x ^= bits_s[pl.cvar[t * pl.m + p]];
+        } else {
+            for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.m + p]];
+        }
         acc |= x;
     }
     if (acc) atomicOr(sh_unsat, acc);
@@ -253,14 +328,22 @@ __device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentA
     }
 }
 
-template <int G, int FORM>
+// LDS carve (bytes): msg at 0, then llr_s, alpha_s, bits_s, the syndrome word
+__host__ __device__ inline size_t res_off_llr(int S, int G) { return (size_t)S * G * 4; }
+__host__ __device__ inline size_t res_off_alpha(int S, int n, int G) { return res_off_llr(S, G) + (size_t)n * G * 4; }
+__host__ __device__ inline size_t res_off_bits(int S, int n, int G, int n_alpha_lds) { return res_off_alpha(S, n, G) + (size_t)n_alpha_lds * 4; }
+__host__ __device__ inline size_t res_off_flag(int S, int n, int G, int n_alpha_lds) { return (res_off_bits(S, n, G, n_alpha_lds) + n + 3) / 4 * 4; }
+__host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
+
+template <int G, int FORM, bool BPC>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
-    extern __shared__ __align__(16) unsigned char res_smem[];
-    float *msg = reinterpret_cast<float *>(res_smem);
-    float *llr_s = msg + (size_t)pl.S * G;
-    uint8_t *bits_s = reinterpret_cast<uint8_t *>(llr_s + (size_t)pl.n * G);
-    __shared__ unsigned sh_unsat;
+    extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
+    const int n_alpha_lds = a.alpha_in_lds ? a.T * a.n_alpha : 0;
+    float *llr_s = reinterpret_cast<float *>(res_smem + res_off_llr(pl.S, G));
+    float *alpha_s = reinterpret_cast<float *>(res_smem + res_off_alpha(pl.S, pl.n, G));
+    uint8_t *bits_s = res_smem + res_off_bits(pl.S, pl.n, G, n_alpha_lds);
+    unsigned *sh_unsat = reinterpret_cast<unsigned *>(res_smem + res_off_flag(pl.S, pl.n, G, n_alpha_lds));
     using P = Pack<float, G>;
     const int tid = threadIdx.x, nt = blockDim.x, n = pl.n;
     const long long b0 = (long long)blockIdx.x * G;
@@ -273,22 +356,30 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const float *row = a.llr + (size_t)(b0 + g) * n;
         for (int j = tid; j < n; j += nt) llr_s[(int)pl.inv_perm_v[j] * G + g] = live ? row[j] : 1.0f;
     }
-    if (tid == 0) sh_unsat = 0;
+    for (int k = tid; k < n_alpha_lds; k += nt) alpha_s[k] = a.alpha[k];
+    if (tid == 0) *sh_unsat = 0;
     __syncthreads();
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
-        P *M = reinterpret_cast<P *>(msg);
         const P *L = reinterpret_cast<const P *>(llr_s);
         for (int q = tid; q < n; q += nt) {
-            const int dv = pl.dv_s[q];
+            const int dv = (int)(pl.vmeta[q] & 0xffu);
+            const uint4 s8 = pl.vslot8[q];
+            const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,
+                                     s8.z & 0xffffu, s8.z >> 16, s8.w & 0xffffu, s8.w >> 16};
             P l = L[q];
             if (a.T == 0) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) l.x[g] = 0.0f;
             }
-            for (int k = 0; k < dv; ++k) M[pl.vslot[k * n + q]] = l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < dv) *reinterpret_cast<P *>(res_smem + off[k]) = l;
         }
     }
+    // first-round check degree (iteration-invariant) and per-check beta of iteration 0, in registers
+    const int dc_pre = tid < pl.m ? pl.dc_s[tid] : 0;
+    float b_pre = (BPC && tid < pl.m && a.T > 0) ? a.beta[pl.bslot_c[tid]] : 0.0f;
     __syncthreads();
 
     unsigned done = 0;                                   // block-uniform
@@ -300,19 +391,24 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const float *beta_row = a.beta + (size_t)it * a.n_beta;
         const float *oa_row = a.oms_alpha ? a.oms_alpha + (size_t)it * a.n_oms_alpha : nullptr;
         const float *thr = FORM == FORM_RCQ ? a.thr + (size_t)a.q_of_iter[it] * a.n_levels : nullptr;
-        res_check_phase<G, FORM>(pl, msg, beta_row, oa_row, thr, a.n_levels, tid, nt);
+        const float *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
+        const float *alpha_glb = a.alpha + (size_t)it * a.n_alpha;
+        if (!(a.debug_skip & 1))
+            res_check_phase<G, FORM, BPC>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, dc_pre, b_pre, tid, nt);
+        if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
+            b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
         __syncthreads();
         if (a.early_stop) {
-            res_var_phase<G, 1>(pl, msg, llr_s, bits_s, nullptr, 0u, tid, nt);
+            res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
             __syncthreads();
-            res_syndrome_phase<G>(pl, bits_s, &sh_unsat, tid, nt);
+            res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
             __syncthreads();
-            const unsigned unsat = sh_unsat;
+            const unsigned unsat = *sh_unsat;
             __syncthreads();
-            if (tid == 0) sh_unsat = 0;
+            if (tid == 0) *sh_unsat = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
-                res_var_phase<G, 1>(pl, msg, llr_s, bits_s, nullptr, newly, tid, nt);
+                res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, newly, tid, nt);
                 __syncthreads();
 #pragma unroll
                 for (int g = 0; g < G; ++g)
@@ -322,8 +418,8 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
                 __syncthreads();
             }
         }
-        if (it != a.T - 1) {
-            res_var_phase<G, 0>(pl, msg, llr_s, bits_s, a.alpha + (size_t)it * a.n_alpha, 0u, tid, nt);
+        if (it != a.T - 1 && !(a.debug_skip & 2)) {
+            res_var_phase<G, 0>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
         }
     }
@@ -331,14 +427,15 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // codewords still open after T iterations: outputs of the last iteration
     const unsigned open = ~done & kAll;
     if (!open) return;
-    res_var_phase<G, 1>(pl, msg, llr_s, bits_s, nullptr, open, tid, nt);
+    if (!(a.debug_skip & 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
     __syncthreads();
     unsigned unsat = kAll;
-    if (!a.early_stop) {                                 // fixed-T mode: success = final syndrome is zero
-        res_syndrome_phase<G>(pl, bits_s, &sh_unsat, tid, nt);
+    if (!a.early_stop && !(a.debug_skip & 8)) {          // fixed-T mode: success = final syndrome is zero
+        res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
         __syncthreads();
-        unsat = sh_unsat;
+        unsat = *sh_unsat;
     }
+    if (a.debug_skip & 4) return;
 #pragma unroll
     for (int g = 0; g < G; ++g)
         if ((open >> g) & 1u) res_emit<G>(pl, a, llr_s, b0 + g, g, a.T, ((unsat >> g) & 1u) ? 0 : 1, tid, nt);
