@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--early-stop", action="store_true", help="reference early-exit semantics instead of fixed T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--no-overlap", action="store_true", help="join every step's all-gather before the next decode")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
     args = ap.parse_args()
 
@@ -155,11 +156,15 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the decode path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; gloo = 1-GPU rehearsal
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     gname, T, default_batch, desc = WORKLOADS[args.workload]
     B = args.batch or default_batch
@@ -170,14 +175,30 @@ def main():
     early = bool(args.early_stop)
 
     from sharding import all_gather_hard_decisions
+    nbytes = (g.n + 7) // 8
+    pending = []          # [(work, gathered, packed_src)] -- the previous step's all-gather, still in flight
 
     def step():
+        """decode this rank's shard, then all-gather the bit-packed hard decisions.  The gather of step k
+        runs on RCCL's stream while step k+1 decodes (separate buffers), and is joined one step later."""
         res = eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post, want_packed=world > 1)
+        gathered = None
         if world > 1:
-            return res, all_gather_hard_decisions(res.packed_bits, B * world)
-        return res, None
+            if backend != "nccl":                                  # rehearsal path: host-side gather
+                gathered = all_gather_hard_decisions(res.packed_bits.cpu(), B * world)
+            elif args.no_overlap:
+                gathered = all_gather_hard_decisions(res.packed_bits, B * world)
+            else:
+                if pending:
+                    pending.pop()[0].wait()
+                gathered = torch.empty((world * B, nbytes), dtype=torch.uint8, device=device)
+                work = dist.all_gather_into_tensor(gathered, res.packed_bits, async_op=True)
+                pending.append((work, gathered, res.packed_bits))
+        return res, gathered
 
     def fence():
+        while pending:
+            pending.pop()[0].wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)

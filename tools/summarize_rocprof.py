@@ -57,8 +57,11 @@ def main():
         data = json.load(open(tj)) if os.path.exists(tj) else {}
         cn = [v for k, v in traffic.items() if k.startswith("ldpc::cn_sweep") and k.rstrip(">").endswith("false")]
         vn = [v for k, v in traffic.items() if k.startswith("ldpc::vn_sweep") and k.rstrip(">").endswith("false")]
-        data[workload] = {"cn_sweep_bytes_per_launch": cn[0] if cn else None,
-                          "vn_sweep_bytes_per_launch": vn[0] if vn else None,
+        res = [v for k, v in traffic.items() if k.startswith("ldpc::resident_decode")]
+        prev = data.get(workload, {})
+        data[workload] = {"cn_sweep_bytes_per_launch": cn[0] if cn else prev.get("cn_sweep_bytes_per_launch"),
+                          "vn_sweep_bytes_per_launch": vn[0] if vn else prev.get("vn_sweep_bytes_per_launch"),
+                          "resident_decode_bytes_per_launch": res[0] if res else prev.get("resident_decode_bytes_per_launch"),
                           "source": f"{tag}_{workload}_pmc.csv", "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
         json.dump(data, open(tj, "w"), indent=1)
         print("wrote", tj)
