@@ -7,6 +7,7 @@ import this package, which does so) and the reference's import lines keep workin
     from ldpc_decoder import LDPCCode, BasicMinSumDecoder, create_test_ldpc_code, simulate_awgn_channel
     from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
     from rcq_decoder import NonUniformQuantizer, RCQMinSumDecoder, WeightedRCQDecoder
+    from neural_minsum_decoder import NeuralMinSumDecoder, NeuralOffsetMinSumDecoder, analyze_weight_patterns
 
 with ``decode`` / ``forward`` executed by hand-written gfx950 kernels behind the C ABI
 of ``include/ldpc_hip.h`` (``libldpc_hip.so`` in this directory, built by
@@ -23,9 +24,13 @@ from ldpc_decoder import (LDPCCode, BasicMinSumDecoder, create_test_ldpc_code,  
                           simulate_awgn_channel)
 from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder  # noqa: E402,F401
 from rcq_decoder import NonUniformQuantizer, RCQMinSumDecoder, WeightedRCQDecoder  # noqa: E402,F401
+from neural_minsum_decoder import (NeuralMinSumDecoder, NeuralOffsetMinSumDecoder,  # noqa: E402,F401
+                                   analyze_weight_patterns)
 from tanner_graph import TannerGraph  # noqa: E402,F401
 from engine import DecodeEngine, DecodeResult  # noqa: E402,F401
 from _native import NativeEngineError, build_native  # noqa: E402,F401
 import codes  # noqa: E402,F401
+from simulation_framework import (SimulationConfig, SimulationResult, LDPSimulator,  # noqa: E402,F401
+                                  create_test_decoders)
 
 PACKAGE_DIR = _here

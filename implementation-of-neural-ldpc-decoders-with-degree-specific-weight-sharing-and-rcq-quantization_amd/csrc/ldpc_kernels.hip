@@ -252,12 +252,15 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
             } else {
                 float w = flip_sign<float>((float)(b * raw), neg);
                 float mag = __builtin_fabsf(w);
-                int lvl = 0;                                                          // rcq_decoder.py:79-85
+                // rcq_decoder.py:79-85: level = last q with mag >= tau_q, default 0 -- the q = 0
+                // comparison cannot change the outcome and is left out
+                int lvl = 0;
                 if (n_levels <= 8) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;
+                    for (int q = 1; q < 8; ++q)
+                        if (q < n_levels) lvl = (mag >= th[q]) ? q : lvl;           // wave-uniform skip
                 } else {
-                    for (int q = 0; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
+                    for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
                 }
                 int code = ((w < 0.0f) ? n_levels : 0) + lvl;                         // :88-89
                 o.x[c] = (OutT)code;

@@ -135,12 +135,15 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
                 // quantise + reconstruct in one go: value = (1 - 2*sign_bit) * tau[level]
                 const float w = __uint_as_float(__float_as_uint(b * raw) ^ sflip);
                 const float mag = __builtin_fabsf(w);
-                float rec = (n_levels <= 8) ? th[0] : thr[0];          // level 0 when nothing matches
+                // level = last q with mag >= tau_q, default 0 -- so the q = 0 comparison can never
+                // change the outcome and is left out (any threshold order, NaN included)
+                float rec = (n_levels <= 8) ? th[0] : thr[0];
                 if (n_levels <= 8) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;
+                    for (int q = 1; q < 8; ++q)
+                        if (q < n_levels) rec = (mag >= th[q]) ? th[q] : rec;       // wave-uniform skip
                 } else {
-                    for (int q = 0; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                    for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
                 }
                 o.x[g] = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
             }

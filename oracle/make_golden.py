@@ -43,6 +43,7 @@ import logging  # noqa: E402
 import ldpc_decoder as ref_ldpc  # noqa: E402  (the reference's)
 import neural_2d_decoder as ref_n2d  # noqa: E402
 import rcq_decoder as ref_rcq  # noqa: E402
+import neural_minsum_decoder as ref_nms  # noqa: E402
 import oracle  # noqa: E402  (oracle/oracle.py)
 
 logging.getLogger().setLevel(logging.WARNING)
@@ -336,6 +337,77 @@ def run_wrcq(code, H, llrs, wtype, T, rng=None, default_init_seed=None, bc=3, qp
                 beta_keys=bk, beta_vals=bv, alpha_keys=ak, alpha_vals=av)
 
 
+def run_offset2d(code, H, llrs, wtype, T, rng):
+    g = oracle.OracleGraph(H)
+    dec = ref_n2d.Neural2DOffsetMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=T)
+    beta, alpha = set_weights(dec, rng, 0.0, 0.6, 0.0, 0.3)
+    bits, post, its = [], [], []
+    with torch.no_grad():
+        for x in llrs:
+            b, p, i = dec(torch.from_numpy(x.copy()))
+            bits.append(b.numpy().copy()); post.append(p.detach().numpy().reshape(-1).copy()); its.append(int(i))
+    bits, post, its = np.stack(bits), np.stack(post), np.asarray(its, np.int32)
+    ob, op, oi, _ = oracle.neural2d_offset(g, llrs, wtype, T, beta, alpha)
+    check_equal("oms2d bits", ob, bits); check_equal("oms2d iters", oi, its)
+    if not np.array_equal(op, post):                       # value equality (the product with a zero sign gives -0.0)
+        raise SystemExit("ORACLE MISMATCH in oms2d posterior")
+    bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+    return dict(llr=llrs, bits=bits.astype(np.uint8), posterior=post, iters=its, wtype=np.int32(wtype), T=np.int32(T),
+                beta_keys=bk, beta_vals=bv, alpha_keys=ak, alpha_vals=av)
+
+
+def run_edge(code, H, llrs, T, offset, seed):
+    """NeuralMinSumDecoder / NeuralOffsetMinSumDecoder with the constructor's own seeded init"""
+    g = oracle.OracleGraph(H)
+    torch.manual_seed(seed)
+    dec = (ref_nms.NeuralOffsetMinSumDecoder if offset else ref_nms.NeuralMinSumDecoder)(code, max_iterations=T)
+    if offset:                                             # spread the offsets so relu() actually clips
+        with torch.no_grad():
+            for p in dec.beta_weights.values():
+                p.mul_(3.0).abs_()
+    beta = {k: float(v.detach().item()) for k, v in dec.beta_weights.items()}
+    bits, post, its = [], [], []
+    with torch.no_grad():
+        for x in llrs:
+            b, p, i = dec(torch.from_numpy(x.copy()))
+            bits.append(b.numpy().copy()); post.append(p.detach().numpy().reshape(-1).copy()); its.append(int(i))
+    bits, post, its = np.stack(bits), np.stack(post), np.asarray(its, np.int32)
+    ob, op, oi, _ = oracle.neural_minsum(g, llrs, T, beta, offset=offset)
+    check_equal("edge bits", ob, bits); check_equal("edge iters", oi, its)
+    if not np.array_equal(op, post):
+        raise SystemExit("ORACLE MISMATCH in edge-weight posterior")
+    bk, bv = pack_weights(beta)
+    return dict(llr=llrs, bits=bits.astype(np.uint8), posterior=post, iters=its, T=np.int32(T), seed=np.int32(seed),
+                offset=np.int32(offset), beta_keys=bk, beta_vals=bv)
+
+
+def gen_offset_and_edge(which):
+    """'next' rows of SURVEY 8f-2: offset forms and per-edge weights, toy + 48x96 codes"""
+    if which == "toy":
+        code = ref_ldpc.create_test_ldpc_code()
+        H = code.H
+        llrs = toy_inputs_fp64(48).astype(np.float32)
+        T = 10
+    else:
+        H = load_edge_list("small_96_48")
+        code = CachedCode(n=96, k=48, H=H, max_iterations=10)
+        rng0 = np.random.default_rng(77)
+        llrs = np.concatenate([awgn_llr_decoder_convention(rng0, 5, 96, 2.0, np.float32),
+                               awgn_llr_decoder_convention(rng0, 5, 96, 5.0, np.float32),
+                               special_llrs(rng0, 96, 4).astype(np.float32)])
+        T = 6
+    rng = np.random.default_rng(2025)
+    out = {"H": np.asarray(H).astype(np.uint8)} if which == "toy" else {"graph": np.asarray("small_96_48")}
+    for wtype in (1, 2, 3, 4):
+        for k, v in run_offset2d(code, H, llrs, wtype, T, rng).items():
+            out[f"o{wtype}_{k}"] = v
+    for k, v in run_edge(code, H, llrs, T, False, 11).items():
+        out[f"nms_{k}"] = v
+    for k, v in run_edge(code, H, llrs, T, True, 12).items():
+        out[f"oms_{k}"] = v
+    return out
+
+
 def toy_inputs_fp64(count):
     """config 1 inputs: np.random.seed(s); simulate_awgn_channel(zeros(7), 2.0) literally
     (ldpc_decoder.py:286-302), then a block of special vectors, then the flipped sign
@@ -480,6 +552,8 @@ SETS = {
     "ira_neural2d": lambda: gen_ira("neural2d"),
     "ira_rcq": lambda: gen_ira("rcq"),
     "ira_wrcq": lambda: gen_ira("wrcq"),
+    "toy_offset_edge": lambda: gen_offset_and_edge("toy"),
+    "small_offset_edge": lambda: gen_offset_and_edge("small"),
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 

@@ -277,6 +277,35 @@ def weighted_rcq(g: OracleGraph, llr, bc: int, quantizer_params, weight_sharing_
                   thresholds=thr, q_of_iter=quantizer_schedule(T, len(quantizer_params)), **kw)
 
 
+def neural2d_offset(g: OracleGraph, llr, weight_sharing_type: int, T: int, beta: Dict[str, float],
+                    alpha: Dict[str, float], early_stop=True, **kw):
+    """Neural2DOffsetMinSumDecoder.forward (neural_2d_decoder.py:338-434): C2V = prod(signs) *
+    (relu(min - beta) - alpha) with both looked up per edge (defaults 0.0), plain V2C sums."""
+    bt, bs, at, as_ = weight_tables(g, weight_sharing_type, T, beta, alpha, beta_default=0.0, alpha_default=0.0)
+    return decode(g, np.asarray(llr, dtype=np.float32), T=T, early_stop=early_stop, c2v_form=C2V_OMS,
+                  sum_order=SUM_TORCH, beta=bt, beta_slot=bs,
+                  alpha=np.ones((max(T, 1), 1), np.float32), alpha_slot=np.zeros(g.n, np.int32),
+                  oms_alpha=at, oms_alpha_slot=as_[g.var_idx], **kw)
+
+
+def edge_weight_table(g: OracleGraph, T: int, beta: Dict[str, float]):
+    """{"iter_{t}_c{i}_v{j}": w} -> [T][E] in CSR edge order (neural_minsum_decoder.py:45-53)"""
+    out = np.zeros((max(T, 1), max(g.E, 1)), dtype=np.float32)
+    for t in range(T):
+        for e in range(g.E):
+            out[t, e] = beta[f"iter_{t}_c{int(g.rows[e])}_v{int(g.var_idx[e])}"]
+    return out
+
+
+def neural_minsum(g: OracleGraph, llr, T: int, beta: Dict[str, float], offset: bool = False, early_stop=True, **kw):
+    """NeuralMinSumDecoder.forward (neural_minsum_decoder.py:58-150) / NeuralOffsetMinSumDecoder.forward
+    (:192-285, offset=True: C2V = prod(signs) * relu(min - beta))."""
+    return decode(g, np.asarray(llr, dtype=np.float32), T=T, early_stop=early_stop,
+                  c2v_form=C2V_OMS if offset else C2V_NMS, sum_order=SUM_TORCH,
+                  beta=edge_weight_table(g, T, beta), beta_slot=np.arange(g.E, dtype=np.int32),
+                  alpha=np.ones((max(T, 1), 1), np.float32), alpha_slot=np.zeros(g.n, np.int32), **kw)
+
+
 def quantize(x, thresholds):
     x = np.ascontiguousarray(x, dtype=np.float32).ravel()
     thr = np.ascontiguousarray(thresholds, dtype=np.float32)

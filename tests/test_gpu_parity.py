@@ -337,6 +337,27 @@ def test_offset_minsum_vs_oracle(gpu_device, oracle_mod):
         assert_post(post.cpu().numpy(), op)
 
 
+@pytest.mark.parametrize("name", ["toy_offset_edge", "small_offset_edge"])
+def test_offset_and_edge_weight_golden(name, gpu_device):
+    """SURVEY 8f-2 rows against the reference's own outputs: Neural2DOffsetMinSumDecoder types 1-4,
+    NeuralMinSumDecoder, NeuralOffsetMinSumDecoder (per-edge weights)"""
+    from neural_2d_decoder import Neural2DOffsetMinSumDecoder
+    from neural_minsum_decoder import NeuralMinSumDecoder, NeuralOffsetMinSumDecoder
+    g = load_golden(name)
+    for w in (1, 2, 3, 4):
+        sub = golden_sub(g, f"o{w}")
+        dec = Neural2DOffsetMinSumDecoder(make_code(g, 10), weight_sharing_type=w, max_iterations=int(sub["T"]))
+        load_weights(dec, sub)
+        check_neural(dec, sub, gpu_device)
+    for tag, cls in (("nms", NeuralMinSumDecoder), ("oms", NeuralOffsetMinSumDecoder)):
+        sub = golden_sub(g, tag)
+        dec = cls(make_code(g, 10), max_iterations=int(sub["T"]))
+        beta = weights_dict(sub["beta_keys"], sub["beta_vals"])
+        assert set(beta) == set(dec.beta_weights.keys())
+        dec.load_state_dict({f"beta_weights.{k}": torch.tensor([v], dtype=torch.float32) for k, v in beta.items()})
+        check_neural(dec, sub, gpu_device)
+
+
 # --------------------------------------------------------------------------------- edge cases
 def odd_code():
     """dense-ish 12x40 code: check degrees > 32 (wide path), variable degrees > 8 (generic

@@ -153,6 +153,35 @@ def test_wrcq_init_and_attributes_match_reference():
         WeightedRCQDecoder(create_test_ldpc_code(), 3, 8, QP, weight_sharing_type=0, max_iterations=2)
 
 
+def test_edge_weight_decoders_init_and_analysis():
+    """NeuralMinSumDecoder / NeuralOffsetMinSumDecoder: 130 parameters at T=10 on the toy code
+    (IMPLEMENTATION_SUMMARY.md:168), reference key names, seed-identical init"""
+    from ldpc_decoder import create_test_ldpc_code
+    from neural_minsum_decoder import NeuralMinSumDecoder, NeuralOffsetMinSumDecoder, analyze_weight_patterns
+    g = load_golden("toy_offset_edge")
+    code = create_test_ldpc_code()
+    sub = golden_sub(g, "nms")
+    torch.manual_seed(int(sub["seed"]))
+    dec = NeuralMinSumDecoder(code, max_iterations=10)
+    assert len(dec.beta_weights) == 130 and "iter_0_c0_v0" in dec.beta_weights and "iter_9_c3_v6" in dec.beta_weights
+    assert {k: float(v.item()) for k, v in dec.beta_weights.items()} == weights_dict(sub["beta_keys"], sub["beta_vals"])
+    W = dec.weight_table()
+    assert W.shape == (10, 13) and abs(float(W.mean()) - 0.7) < 0.05
+    an = analyze_weight_patterns(dec, code)
+    assert set(an) == {"weight_statistics", "iteration_patterns", "node_degree_correlations"}
+    assert sorted(an["iteration_patterns"]) == list(range(10))
+    assert set(an["node_degree_correlations"]) == {"check_degree_3", "check_degree_4"}
+    assert an["node_degree_correlations"]["check_degree_3"]["count"] == 9
+    np.testing.assert_allclose(an["iteration_patterns"][0]["mean"], W[0].astype(np.float64).mean())
+    sub = golden_sub(g, "oms")
+    torch.manual_seed(int(sub["seed"]))
+    dec = NeuralOffsetMinSumDecoder(code, max_iterations=10)
+    with torch.no_grad():
+        for p in dec.beta_weights.values():
+            p.mul_(3.0).abs_()                       # the transformation the golden generator applied
+    assert {k: float(v.item()) for k, v in dec.beta_weights.items()} == weights_dict(sub["beta_keys"], sub["beta_vals"])
+
+
 def test_quantizer_utility_known_answers():
     from rcq_decoder import NonUniformQuantizer
     g = load_golden("quantizer")

@@ -146,6 +146,28 @@ def test_dvbs2_wrcq_golden(oracle_mod):
     _check_wrcq(oracle_mod, graph_of(oracle_mod, g), g)
 
 
+@pytest.mark.parametrize("name", ["toy_offset_edge", "small_offset_edge"])
+def test_offset_and_edge_weight_golden(name, oracle_mod):
+    """Neural2DOffsetMinSumDecoder types 1-4, NeuralMinSumDecoder, NeuralOffsetMinSumDecoder"""
+    g = load_golden(name)
+    og = graph_of(oracle_mod, g)
+    for w in (1, 2, 3, 4):
+        sub = golden_sub(g, f"o{w}")
+        beta = weights_dict(sub["beta_keys"], sub["beta_vals"])
+        alpha = weights_dict(sub["alpha_keys"], sub["alpha_vals"])
+        bits, post, iters, _ = oracle_mod.neural2d_offset(og, sub["llr"], w, int(sub["T"]), beta, alpha)
+        np.testing.assert_array_equal(bits, sub["bits"])
+        np.testing.assert_array_equal(iters, sub["iters"])
+        np.testing.assert_array_equal(post, sub["posterior"])
+    for tag, offset in (("nms", False), ("oms", True)):
+        sub = golden_sub(g, tag)
+        beta = weights_dict(sub["beta_keys"], sub["beta_vals"])
+        bits, post, iters, _ = oracle_mod.neural_minsum(og, sub["llr"], int(sub["T"]), beta, offset=offset)
+        np.testing.assert_array_equal(bits, sub["bits"])
+        np.testing.assert_array_equal(iters, sub["iters"])
+        np.testing.assert_array_equal(post, sub["posterior"])
+
+
 # ------------------------------------------------------------------ oracle self-consistency
 def test_fixed_iteration_mode_and_threads(oracle_mod):
     """early_stop=False runs T iterations; success = final syndrome; threads do not change results"""
