@@ -166,7 +166,16 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
         if (first) LDPC_CN(FORM_OMS, true); else LDPC_CN(FORM_OMS, false);
     } else {
         if constexpr (sizeof(T) == 4) {
-            if (first) LDPC_CN(FORM_RCQ, true); else LDPC_CN(FORM_RCQ, false);
+            if (d->n_levels == 4) {                      // bc = 3: compare chain with a compile-time length
+                if (first)
+                    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, true, 4>), grid, block, 0, s, g, src, (void *)w.c2v,
+                                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb);
+                else
+                    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, false, 4>), grid, block, 0, s, g, src, (void *)w.c2v,
+                                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb);
+            } else {
+                if (first) LDPC_CN(FORM_RCQ, true); else LDPC_CN(FORM_RCQ, false);
+            }
         } else {
             return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
         }
@@ -400,15 +409,16 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
 {
     const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
     const size_t lds = d->res_lds;
-#define LDPC_RES(FORM)                                                                                   \
+#define LDPC_RES(FORM, NL)                                                                               \
     do {                                                                                                 \
-        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true> : resident_decode<G, FORM, false>;    \
+        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true, NL> : resident_decode<G, FORM, false, NL>; \
         HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
     } while (0)
-    if (d->form == LDPC_C2V_NMS) LDPC_RES(FORM_NMS);
-    else if (d->form == LDPC_C2V_OMS) LDPC_RES(FORM_OMS);
-    else LDPC_RES(FORM_RCQ);
+    if (d->form == LDPC_C2V_NMS) LDPC_RES(FORM_NMS, 0);
+    else if (d->form == LDPC_C2V_OMS) LDPC_RES(FORM_OMS, 0);
+    else if (d->n_levels == 4) LDPC_RES(FORM_RCQ, 4);       // bc = 3, the paper's and the benchmark's quantiser
+    else LDPC_RES(FORM_RCQ, 0);
 #undef LDPC_RES
     HIP_TRY(hipGetLastError());
     return LDPC_OK;

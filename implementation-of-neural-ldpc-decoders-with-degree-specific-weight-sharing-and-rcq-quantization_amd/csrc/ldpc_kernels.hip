@@ -155,7 +155,7 @@ __device__ __forceinline__ void store_masked(T *p, const Pack<T, VEC> &v, const 
 // FIRST: iteration 0 reads llr[var] instead of v2c (the reference's "initialize with
 // channel LLRs", neural_2d_decoder.py:153-157, folded into the first sweep).
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int FORM, bool FIRST>
+template <typename T, int VEC, int FORM, bool FIRST, int NL = 0>
 __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restrict__ src,
                                                    void *__restrict__ c2v_out,
                                                    const T *__restrict__ beta_row,
@@ -255,10 +255,12 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
                 // rcq_decoder.py:79-85: level = last q with mag >= tau_q, default 0 -- the q = 0
                 // comparison cannot change the outcome and is left out
                 int lvl = 0;
-                if (n_levels <= 8) {
+                if constexpr (NL > 0) {                                   // compile-time level count (bc = 3: 4)
 #pragma unroll
-                    for (int q = 1; q < 8; ++q)
-                        if (q < n_levels) lvl = (mag >= th[q]) ? q : lvl;           // wave-uniform skip
+                    for (int q = 1; q < NL; ++q) lvl = (mag >= th[q]) ? q : lvl;
+                } else if (n_levels <= 8) {
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;       // NaN padding never matches
                 } else {
                     for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
                 }

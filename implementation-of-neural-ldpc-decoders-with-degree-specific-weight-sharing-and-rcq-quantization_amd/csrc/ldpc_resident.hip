@@ -73,7 +73,7 @@ __device__ __forceinline__ bool wave_uniform(int v, int &vw)
 //           |x| == min1 -- on a tie min2 == min1, so which tied edge "is" the arg-min is
 //           value-irrelevant, exactly as with the reference's first-index argmin -- and the sign of
 //           the product of the OTHER signs is bit 31 of (signs ^ x).
-template <int G, int FORM, bool BPC, bool UNI>
+template <int G, int FORM, bool BPC, bool UNI, int NL>
 __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned char *smem, int p, int dc, int dcw,
                                                float b_check, const float *__restrict__ beta_row,
                                                const float *__restrict__ oa_row, const float (&th)[8],
@@ -138,10 +138,12 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
                 // level = last q with mag >= tau_q, default 0 -- so the q = 0 comparison can never
                 // change the outcome and is left out (any threshold order, NaN included)
                 float rec = (n_levels <= 8) ? th[0] : thr[0];
-                if (n_levels <= 8) {
+                if constexpr (NL > 0) {                                   // compile-time level count (bc = 3: 4)
 #pragma unroll
-                    for (int q = 1; q < 8; ++q)
-                        if (q < n_levels) rec = (mag >= th[q]) ? th[q] : rec;       // wave-uniform skip
+                    for (int q = 1; q < NL; ++q) rec = (mag >= th[q]) ? th[q] : rec;
+                } else if (n_levels <= 8) {
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;   // NaN padding never matches
                 } else {
                     for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
                 }
@@ -156,7 +158,7 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
 
 // `dc_pre` / `b_pre` are the first round's degree and per-check beta, fetched by the caller ahead of
 // the barrier so their global-memory latency is off the critical path.
-template <int G, int FORM, bool BPC>
+template <int G, int FORM, bool BPC, int NL>
 __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned char *smem,
                                                 const float *__restrict__ beta_row,
                                                 const float *__restrict__ oa_row,
@@ -177,9 +179,9 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
         }
         int dcw;
         if (wave_uniform(dc, dcw))
-            res_check_body<G, FORM, BPC, true>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
+            res_check_body<G, FORM, BPC, true, NL>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
         else
-            res_check_body<G, FORM, BPC, false>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
+            res_check_body<G, FORM, BPC, false, NL>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
     }
 }
 
@@ -338,7 +340,7 @@ __host__ __device__ inline size_t res_off_bits(int S, int n, int G, int n_alpha_
 __host__ __device__ inline size_t res_off_flag(int S, int n, int G, int n_alpha_lds) { return (res_off_bits(S, n, G, n_alpha_lds) + n + 3) / 4 * 4; }
 __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
 
-template <int G, int FORM, bool BPC>
+template <int G, int FORM, bool BPC, int NL>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const float *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
         const float *alpha_glb = a.alpha + (size_t)it * a.n_alpha;
         if (!(a.debug_skip & 1))
-            res_check_phase<G, FORM, BPC>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, dc_pre, b_pre, tid, nt);
+            res_check_phase<G, FORM, BPC, NL>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
         __syncthreads();
