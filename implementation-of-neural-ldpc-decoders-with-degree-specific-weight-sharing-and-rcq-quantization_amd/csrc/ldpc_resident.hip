@@ -353,13 +353,15 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     const int tid = threadIdx.x, nt = blockDim.x, n = pl.n;
     const long long b0 = (long long)blockIdx.x * G;
     constexpr unsigned kAll = (1u << G) - 1u;
+    if (a.debug_skip & 64) return;                       // launch-overhead probe
 
     // LLRs: coalesced rows from HBM, scattered into degree-sorted order; padding codewords get +1
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const bool live = b0 + g < a.batch;
         const float *row = a.llr + (size_t)(b0 + g) * n;
-        for (int j = tid; j < n; j += nt) llr_s[(int)pl.inv_perm_v[j] * G + g] = live ? row[j] : 1.0f;
+        if (!(a.debug_skip & 16))
+            for (int j = tid; j < n; j += nt) llr_s[(int)pl.inv_perm_v[j] * G + g] = live ? row[j] : 1.0f;
     }
     for (int k = tid; k < n_alpha_lds; k += nt) alpha_s[k] = a.alpha[k];
     if (tid == 0) *sh_unsat = 0;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
         const P *L = reinterpret_cast<const P *>(llr_s);
-        for (int q = tid; q < n; q += nt) {
+        for (int q = tid; q < n && !(a.debug_skip & 32); q += nt) {
             const int dv = (int)(pl.vmeta[q] & 0xffu);
             const uint4 s8 = pl.vslot8[q];
             const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,

@@ -408,6 +408,75 @@ def test_odd_degrees_and_iteration_counts(T, gpu_device, oracle_mod):
     np.testing.assert_array_equal(bits.cpu().numpy(), ob)
 
 
+def sparse_odd_code():
+    """14x40 sparse code that QUALIFIES for the LDS-resident engine (dc <= 32, dv <= 8) and still has a
+    degree-1 check, an empty check, an isolated variable and a degree-1 variable"""
+    from ldpc_decoder import LDPCCode
+    rng = np.random.default_rng(21)
+    H = (rng.random((14, 40)) < 0.12).astype(np.int64)
+    H[12, :] = 0; H[12, 7] = 1          # degree-1 check
+    H[13, :] = 0                        # empty check
+    H[:, 39] = 0                        # isolated variable
+    H[:, 38] = 0; H[3, 38] = 1          # degree-1 variable
+    assert H.sum(axis=0).max() <= 8
+    return LDPCCode(n=40, k=26, H=H, max_iterations=5)
+
+
+@pytest.mark.parametrize("T", [0, 1, 2, 5])
+@pytest.mark.parametrize("B", [1, 2, 3, 130])
+def test_resident_engine_edge_cases(T, B, gpu_device, oracle_mod, engine_mode):
+    """iteration counts 0/1/2, odd batches (padding codeword inside a workgroup), degenerate nodes --
+    on a code the resident engine accepts (so 'auto' really exercises it)"""
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
+    from rcq_decoder import WeightedRCQDecoder
+    from weight_sharing import SharingLayout
+    code = sparse_odd_code()
+    og = oracle_mod.OracleGraph(code.H)
+    rng = np.random.default_rng(100 * T + B)
+    llr = (rng.standard_normal((B, 40)) * 3).astype(np.float32)
+    llr[0, 5] = 0.0
+    if B > 2:
+        llr[2] = np.round(llr[2])
+        llr[1] = np.abs(llr[1]) + 4.0                    # converges at once: early-stop emit at iteration 1
+    x = torch.from_numpy(llr).to(gpu_device)
+    for early in (True, False):
+        dec = Neural2DMinSumDecoder(code, weight_sharing_type=1, max_iterations=T)
+        beta, alpha = rand_weights(dec, rng)
+        bits, post, iters = dec(x, early_stop=early)
+        if engine_mode == "auto":
+            assert dec._engine.info()["engine"] == "resident"
+        ob, op, oi, _ = oracle_mod.neural2d(og, llr, 1, T, beta, alpha, early_stop=early)
+        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+        assert_post(post.cpu().numpy(), op)
+        res = dec._engine.decode(x, early_stop=early, want_packed=True)
+        osucc = oracle_mod.neural2d(og, llr, 1, T, beta, alpha, early_stop=early)[3]
+        np.testing.assert_array_equal(res.success.cpu().numpy(), osucc)
+        unpacked = ((res.packed_bits.cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :40]
+        np.testing.assert_array_equal(unpacked, ob)
+
+        w = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=2, max_iterations=T)
+        beta, alpha = rand_weights(w, rng)
+        bits, post, iters = w(x, early_stop=early)
+        ob, op, oi, _ = oracle_mod.weighted_rcq(og, llr, 3, QP, 2, T, beta, alpha, early_stop=early)
+        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+        np.testing.assert_array_equal(post.cpu().numpy(), op)
+
+        o = Neural2DOffsetMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+        with torch.no_grad():
+            for p in o.beta_weights.values():
+                p.fill_(float(np.float32(rng.uniform(0.0, 0.6))))
+            for p in o.alpha_weights.values():
+                p.fill_(float(np.float32(rng.uniform(0.0, 0.3))))
+        bits, post, iters = o(x, early_stop=early)
+        ob, op, oi, _ = oracle_mod.neural2d_offset(og, llr, 2, T, {k: float(v.item()) for k, v in o.beta_weights.items()},
+                                                   {k: float(v.item()) for k, v in o.alpha_weights.items()}, early_stop=early)
+        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+        assert_post(post.cpu().numpy(), op)
+
+
 def test_error_behaviour(gpu_device):
     from ldpc_decoder import BasicMinSumDecoder, create_test_ldpc_code
     from neural_2d_decoder import Neural2DMinSumDecoder
