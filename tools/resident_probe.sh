@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/probe; mkdir -p $O
+# needs a probe build: python -c "import _native; _native.build_native(force=True, defines=[\"LDPC_RESIDENT_PROBES\"])"
 for d in 0 1 2 3; do
   echo -n "debug_skip=$d "; LDPC_RES_DEBUG=$d python tools/time_sweeps.py --workload basic --tag skip$d 2>/dev/null | grep "^{" | cut -c1-120
 done
@@ -9,6 +10,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_
 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d $O/pmc3 -- python tools/time_sweeps.py --workload basic > $O/pmc3.log 2>&1
 python - <<'PY'
 import csv,glob,collections
+# needs a probe build: python -c "import _native; _native.build_native(force=True, defines=[\"LDPC_RESIDENT_PROBES\"])"
 for d in ("pmc1","pmc2","pmc3"):
     fs=glob.glob(f"gpurun_out/probe/{d}/**/*_counter_collection.csv",recursive=True)
     if not fs: print(d,"no output"); continue
