@@ -56,10 +56,16 @@ struct ResidentArgs {
     const float *thr; int n_levels; const int *q_of_iter;
     int *bits; float *posterior; int *iterations; uint8_t *success; uint8_t *packed;
     int alpha_in_lds;             // T * n_alpha floats staged in LDS
-    int debug_skip;               // timing experiments only (LDPC_RES_DEBUG): bit0 skip check phase, bit1 skip variable phase
+    int debug_skip;               // phase-timing probes, compiled in only with -DLDPC_RESIDENT_PROBES (tools/resident_probe*.sh)
 };
 
 constexpr int kResAlphaMax = 1024;   // floats of alpha table kept in LDS
+
+#ifdef LDPC_RESIDENT_PROBES
+#define LDPC_PROBE(a, bit) ((a).debug_skip & (bit))
+#else
+#define LDPC_PROBE(a, bit) 0
+#endif
 
 __device__ __forceinline__ bool wave_uniform(int v, int &vw)
 {
@@ -353,14 +359,14 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     const int tid = threadIdx.x, nt = blockDim.x, n = pl.n;
     const long long b0 = (long long)blockIdx.x * G;
     constexpr unsigned kAll = (1u << G) - 1u;
-    if (a.debug_skip & 64) return;                       // launch-overhead probe
+    if (LDPC_PROBE(a, 64)) return;                       // launch-overhead probe
 
     // LLRs: coalesced rows from HBM, scattered into degree-sorted order; padding codewords get +1
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const bool live = b0 + g < a.batch;
         const float *row = a.llr + (size_t)(b0 + g) * n;
-        if (!(a.debug_skip & 16))
+        if (!LDPC_PROBE(a, 16))
             for (int j = tid; j < n; j += nt) llr_s[(int)pl.inv_perm_v[j] * G + g] = live ? row[j] : 1.0f;
     }
     for (int k = tid; k < n_alpha_lds; k += nt) alpha_s[k] = a.alpha[k];
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
         const P *L = reinterpret_cast<const P *>(llr_s);
-        for (int q = tid; q < n && !(a.debug_skip & 32); q += nt) {
+        for (int q = tid; q < n && !LDPC_PROBE(a, 32); q += nt) {
             const int dv = (int)(pl.vmeta[q] & 0xffu);
             const uint4 s8 = pl.vslot8[q];
             const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const float *thr = FORM == FORM_RCQ ? a.thr + (size_t)a.q_of_iter[it] * a.n_levels : nullptr;
         const float *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
         const float *alpha_glb = a.alpha + (size_t)it * a.n_alpha;
-        if (!(a.debug_skip & 1))
+        if (!LDPC_PROBE(a, 1))
             res_check_phase<G, FORM, BPC, NL>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
                 __syncthreads();
             }
         }
-        if (it != a.T - 1 && !(a.debug_skip & 2)) {
+        if (it != a.T - 1 && !LDPC_PROBE(a, 2)) {
             res_var_phase<G, 0>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
         }
@@ -434,15 +440,15 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // codewords still open after T iterations: outputs of the last iteration
     const unsigned open = ~done & kAll;
     if (!open) return;
-    if (!(a.debug_skip & 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
+    if (!LDPC_PROBE(a, 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
     __syncthreads();
     unsigned unsat = kAll;
-    if (!a.early_stop && !(a.debug_skip & 8)) {          // fixed-T mode: success = final syndrome is zero
+    if (!a.early_stop && !LDPC_PROBE(a, 8)) {          // fixed-T mode: success = final syndrome is zero
         res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
     }
-    if (a.debug_skip & 4) return;
+    if (LDPC_PROBE(a, 4)) return;
 #pragma unroll
     for (int g = 0; g < G; ++g)
         if ((open >> g) & 1u) res_emit<G>(pl, a, llr_s, b0 + g, g, a.T, ((unsat >> g) & 1u) ? 0 : 1, tid, nt);
