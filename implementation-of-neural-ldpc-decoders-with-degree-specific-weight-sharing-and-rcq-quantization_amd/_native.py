@@ -26,6 +26,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip.h")
 LDPC_F32, LDPC_F64 = 0, 1
 C2V_NMS, C2V_RCQ, C2V_OMS = 0, 1, 2
 MODE_AUTO, MODE_STREAM, MODE_RESIDENT = 0, 1, 2
+SCHED_FLOODING, SCHED_LAYERED_REF = 0, 1
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off",       # the reference never fuses llr + alpha*sum
@@ -62,7 +63,8 @@ class DecoderDesc(C.Structure):
                 ("n_alpha_slots", C.c_int32), ("alpha", C.c_void_p), ("alpha_slot", C.c_void_p),
                 ("n_levels", C.c_int32), ("n_quantizers", C.c_int32), ("thresholds", C.c_void_p),
                 ("q_of_iter", C.c_void_p),
-                ("n_oms_alpha_slots", C.c_int32), ("oms_alpha", C.c_void_p), ("oms_alpha_slot", C.c_void_p)]
+                ("n_oms_alpha_slots", C.c_int32), ("oms_alpha", C.c_void_p), ("oms_alpha_slot", C.c_void_p),
+                ("schedule", C.c_int32)]
 
 
 # every symbol include/ldpc_hip.h declares (tests check the library exports them all)

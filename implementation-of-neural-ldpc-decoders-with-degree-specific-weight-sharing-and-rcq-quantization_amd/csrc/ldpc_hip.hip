@@ -86,6 +86,7 @@ struct ldpc_decoder {
     int *q_of_iter_dev = nullptr;  // device copy (frozen codewords look their quantiser up)
     size_t elem() const { return dtype == LDPC_F64 ? 8 : 4; }
     // LDS-resident engine (ldpc_resident.hip): built at creation when the code qualifies
+    int schedule = 0;              // LDPC_SCHED_*
     int mode = 0;                  // LDPC_MODE_*
     bool res_ok = false;
     int res_G = 0, res_NT = 0;
@@ -238,6 +239,28 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     }
     HIP_TRY(hipGetLastError());
 
+    if (d->schedule == LDPC_SCHED_LAYERED_REF) {
+        if constexpr (sizeof(T) == 4) {
+            // posteriors start as the LLRs and are updated in place, check after check, by one wave per tile
+            hipLaunchKernelGGL((layered_rcq<VEC>), dim3(w.tiles), dim3(kWave), 0, s, g, (float *)w.llrT, d->thresholds,
+                               d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters);
+            HIP_TRY(hipGetLastError());
+            if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
+            if (bits || posterior)
+                hipLaunchKernelGGL((transpose_out<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+                                   (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+            if (iterations || success || packed) {
+                long long threads = batch;
+                if (packed) threads = std::max<long long>(threads, std::min<long long>(batch * ((g.n + 7) / 8), 1ll << 22));
+                hipLaunchKernelGGL((finalize_out<VEC>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, w.done,
+                                   w.iters, w.bitsT, iterations, success, packed, (long long)batch, g.n);
+            }
+            HIP_TRY(hipGetLastError());
+            return LDPC_OK;
+        } else {
+            return fail(LDPC_ERR_UNSUPPORTED, "layered schedule is fp32 only");
+        }
+    }
     if (T_it == 0) {
         // no iteration ran: c2v == 0, posterior = llr + 0  (loop skipped, ldpc_decoder.py:147-153)
         const size_t c2v_bytes = (size_t)w.tiles * W * std::max(g.E, 1) * (d->form == LDPC_C2V_RCQ ? 1 : sizeof(T));
@@ -603,6 +626,12 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
     // association orders restated on the device: torch.sum below its cascade level, np.sum one block
     if (desc->dtype == LDPC_F32 && g->max_dv > 575) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 575 (fp32 sum order)", g->max_dv);
     if (desc->dtype == LDPC_F64 && g->max_dv > 128) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 128 (fp64 sum order)", g->max_dv);
+    if (desc->schedule != LDPC_SCHED_FLOODING && desc->schedule != LDPC_SCHED_LAYERED_REF) return fail(LDPC_ERR_ARG, "bad schedule");
+    if (desc->schedule == LDPC_SCHED_LAYERED_REF) {
+        if (desc->c2v_form != LDPC_C2V_RCQ || desc->dtype != LDPC_F32)
+            return fail(LDPC_ERR_UNSUPPORTED, "the layered schedule exists for the fp32 RCQ decoder only (rcq_decoder.py:281-350)");
+        if (g->m == 1) return fail(LDPC_ERR_UNSUPPORTED, "layered schedule on a single-check code");
+    }
     if (desc->c2v_form == LDPC_C2V_RCQ) {
         if (desc->dtype != LDPC_F32) return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
         if (desc->n_levels < 1 || desc->n_levels > 128) return fail(LDPC_ERR_UNSUPPORTED, "n_levels %d outside 1..128 (bc 1..8)", desc->n_levels);
@@ -619,7 +648,7 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
     DeviceGuard guard(g->device);
     ldpc_decoder *d = new (std::nothrow) ldpc_decoder();
     if (!d) return fail(LDPC_ERR_ARG, "out of host memory");
-    d->g = g; d->dtype = desc->dtype; d->form = desc->c2v_form; d->T = desc->iters;
+    d->g = g; d->dtype = desc->dtype; d->form = desc->c2v_form; d->T = desc->iters; d->schedule = desc->schedule;
     d->n_beta = desc->n_beta_slots; d->n_alpha = desc->n_alpha_slots;
     const size_t es = d->elem();
     const size_t rows = (size_t)std::max(d->T, 1);
@@ -662,7 +691,7 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
         rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
         if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
     }
-    if (!rc) rc = build_resident_plan(d, desc);
+    if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
     if (rc) {
         ldpc_decoder_destroy(d);
         return rc;

@@ -614,6 +614,116 @@ __global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint6
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Reference-compatible "layered" RCQ schedule (RCQMinSumDecoder._decode_layered,
+// rcq_decoder.py:281-350).  As written there the per-check message matrix is re-created for every
+// check, so the "subtract the previous message" step never finds anything to subtract on a code
+// with more than one check: posteriors accumulate every check's quantised message, check after
+// check, inside and across iterations.  That sequential update is what this kernel reproduces.
+// One wave owns W codewords (one tile of the posterior array post[tile][n][W], initialised with the
+// LLRs) and walks the checks in order, so no inter-wave synchronisation exists at all; the
+// parallelism is the batch.  Per check: pass 1 gathers the dc posterior rows (min1/min2/sign
+// parity), pass 2 re-reads each row, quantises-reconstructs sign*min and adds it in place.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restrict__ post,
+                                                     const float *__restrict__ thresholds, int n_levels,
+                                                     const int *__restrict__ q_of_iter, int T, int early_stop,
+                                                     uint64_t *__restrict__ bitsT, uint64_t *__restrict__ done,
+                                                     int *__restrict__ iters)
+{
+    constexpr int W = kWave * VEC;
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    float *P = post + (size_t)tile * g.n * W + (size_t)lane * VEC;
+    unsigned frozen = 0;                                    // bit c: codeword c of this lane has stopped
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) frozen |= (unsigned)((done[(size_t)tile * VEC + c] >> lane) & 1ull) << c;
+    const unsigned kAll = (1u << VEC) - 1u;
+
+    auto syndrome = [&]() {                                 // bit c set: some check of codeword c is unsatisfied
+        unsigned unsat = 0;
+        for (int i = 0; i < g.m; ++i) {
+            const int e0 = g.check_ptr[i], e1 = g.check_ptr[i + 1];
+            unsigned par = 0;
+            for (int e = e0; e < e1; ++e) {
+                const Pack<float, VEC> v = ld<float, VEC>(P + (size_t)g.var_idx[e] * W);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) par ^= (v.x[c] < 0.0f ? 1u : 0u) << c;
+            }
+            unsat |= par;
+        }
+        return unsat;
+    };
+
+    for (int it = 0; it < T; ++it) {
+        if (early_stop && __ballot(frozen != kAll) == 0ull) break;
+        const float *thr = thresholds + (size_t)q_of_iter[it] * n_levels;
+        for (int i = 0; i < g.m; ++i) {
+            const int e0 = uni(g.check_ptr[i]);
+            const int dc = uni(g.check_ptr[i + 1]) - e0;
+            if (dc == 0) continue;
+            float m1[VEC], m2[VEC];
+            unsigned par[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); par[c] = 0; }
+#pragma unroll 4
+            for (int t = 0; t < dc; ++t) {
+                const Pack<float, VEC> v = ld<float, VEC>(P + (size_t)g.var_idx[e0 + t] * W);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const float a = __builtin_fabsf(v.x[c]);
+                    par[c] ^= signbit_of<float>(v.x[c]);
+                    if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; }
+                    else if (a < m2[c]) { m2[c] = a; }
+                }
+            }
+            if (dc == 1) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) m2[c] = m1[c];
+            }
+#pragma unroll 2
+            for (int t = 0; t < dc; ++t) {
+                float *row = P + (size_t)g.var_idx[e0 + t] * W;
+                Pack<float, VEC> v = ld<float, VEC>(row);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const float a = __builtin_fabsf(v.x[c]);
+                    const float raw = (a == m1[c]) ? m2[c] : m1[c];       // arg-min edge; ties make min2 == min1
+                    const float w = flip_sign<float>(raw, par[c] ^ signbit_of<float>(v.x[c]));
+                    const float mag = __builtin_fabsf(w);
+                    float rec = thr[0];
+                    for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                    const float msg = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
+                    if (!((frozen >> c) & 1u)) v.x[c] = v.x[c] + msg;
+                }
+                if (frozen != kAll) st<float, VEC>(row, v);
+            }
+        }
+        if (early_stop) {
+            const unsigned newly = ~syndrome() & ~frozen & kAll;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c)
+                if ((newly >> c) & 1u) iters[(size_t)tile * W + lane * VEC + c] = it + 1;
+            frozen |= newly;
+        }
+    }
+    unsigned ok = frozen;
+    if (!early_stop) ok = ~syndrome() & kAll;               // fixed-T mode: success = final syndrome is zero
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const uint64_t m = __ballot((ok >> c) & 1u);
+        if (lane == 0) done[(size_t)tile * VEC + c] = m;
+    }
+    for (int j = 0; j < g.n; ++j) {                         // hard decisions as ballots, like the sweep engine
+        const Pack<float, VEC> v = ld<float, VEC>(P + (size_t)j * W);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const uint64_t m = __ballot(v.x[c] < 0.0f);
+            if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = m;
+        }
+    }
+}
+
 // done masks: padding codewords (>= batch) start frozen; iterations start at T
 template <int VEC>
 __global__ void init_state(uint64_t *__restrict__ done, int *__restrict__ iters, long long batch,

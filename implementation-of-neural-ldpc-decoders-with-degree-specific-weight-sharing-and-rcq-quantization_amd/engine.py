@@ -88,7 +88,7 @@ class DecodeEngine:
                  beta: np.ndarray, beta_slot: np.ndarray, alpha: np.ndarray, alpha_slot: np.ndarray,
                  thresholds: Optional[np.ndarray] = None, q_of_iter: Optional[np.ndarray] = None,
                  oms_alpha: Optional[np.ndarray] = None, oms_alpha_slot: Optional[np.ndarray] = None,
-                 device=None):
+                 schedule: int = nat.SCHED_FLOODING, device=None):
         if dtype not in (torch.float32, torch.float64):
             raise TypeError("engine dtype must be float32 or float64")
         self.device = _require_gpu(device)
@@ -110,6 +110,7 @@ class DecodeEngine:
         desc = nat.DecoderDesc()
         desc.dtype = nat.LDPC_F32 if dtype == torch.float32 else nat.LDPC_F64
         desc.c2v_form, desc.iters = self.c2v_form, self.iters
+        desc.schedule = int(schedule)
         desc.n_beta_slots, desc.beta, desc.beta_slot = beta.shape[1], nat.ptr(beta), nat.ptr(beta_slot)
         desc.n_alpha_slots, desc.alpha, desc.alpha_slot = alpha.shape[1], nat.ptr(alpha), nat.ptr(alpha_slot)
         keep = [beta, alpha, beta_slot, alpha_slot]

@@ -16,8 +16,12 @@ Reference behaviour mirrored (file:line in /root/reference):
       ``layered`` stored and ignored by forward as in the reference
                                                                rcq_decoder.py:352-597
 
-Not implemented: ``RCQMinSumDecoder(layered=True)`` (rcq_decoder.py:281-350; SURVEY.md
-8f-3 "next") raises NotImplementedError instead of silently running another schedule.
+``RCQMinSumDecoder(layered=True)`` runs the reference's layered schedule exactly as the
+reference executes it (rcq_decoder.py:281-350): checks in order on running
+posteriors; because the reference re-creates its message matrix for every check, the
+"previous message" it subtracts is always zero, and so it is here (bug-compatible by decision --
+parity is the contract; a single-check code, the one case where the subtraction would be real,
+is rejected).
 
 Extensions: batched ``[B, n]`` input and ``early_stop=False`` as in the other decoders.
 """
@@ -131,11 +135,12 @@ class RCQMinSumDecoder:
         g = self.code.tanner_graph()
         T = int(self.max_iterations)
         thr = _threshold_table(self.quantizers)
-        key = (dev.index, id(g), T, thr.tobytes())
+        key = (dev.index, id(g), T, thr.tobytes(), bool(self.layered))
         if self._engine is None or self._engine_key != key:
             rows = max(T, 1)
             self._engine = DecodeEngine(
                 g, dtype=torch.float32, c2v_form=nat.C2V_RCQ, iters=T, device=dev,
+                schedule=nat.SCHED_LAYERED_REF if self.layered else nat.SCHED_FLOODING,
                 beta=np.ones((rows, 1), np.float32), beta_slot=np.zeros(g.E, np.int32),     # prod(signs) * min
                 alpha=np.ones((rows, 1), np.float32), alpha_slot=np.zeros(g.n, np.int32),   # llr + sum(others)
                 thresholds=thr, q_of_iter=_quantizer_schedule(len(self.quantizers), T))
@@ -149,8 +154,6 @@ class RCQMinSumDecoder:
         Returns:
             decoded_bits (int32), success (bool / bool[B]), iterations (int / int32[B])
         """
-        if self.layered:
-            raise NotImplementedError("layered RCQ schedule (rcq_decoder.py:281-350) is not part of the engine yet")
         if not isinstance(llr, torch.Tensor):
             raise TypeError("llr must be a torch.Tensor")    # the reference needs llr.device as well
         _, x, single = _as_batch(llr, self.code.n)

@@ -109,8 +109,6 @@ def _engine_of(decoder, device):
     if isinstance(decoder, BasicMinSumDecoder):
         return decoder._engine(torch.float32, device)
     if hasattr(decoder, "_get_engine"):
-        if getattr(decoder, "layered", False) and isinstance(decoder, RCQMinSumDecoder):
-            raise NotImplementedError("layered RCQ schedule is not part of the engine yet")
         return decoder._get_engine(device)
     raise TypeError(f"{type(decoder).__name__} is not one of this package's decoders")
 

@@ -55,6 +55,11 @@ enum {
     LDPC_C2V_OMS = 2   /* c2v = s * (relu(min - beta) - a_c) neural_2d_decoder.py:400-401                          */
 };
 
+/* message schedule.  LAYERED_REF is RCQMinSumDecoder(layered=True) exactly as the reference runs it
+ * (rcq_decoder.py:281-350): checks processed in order on running posteriors whose "previous
+ * message" is never subtracted (the reference re-creates its message matrix per check); RCQ fp32 only. */
+enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED_REF = 1 };
+
 typedef struct ldpc_graph ldpc_graph;      /* Tanner graph, CSR + CSC, device resident */
 typedef struct ldpc_decoder ldpc_decoder;  /* graph + weight tables + quantiser LUTs    */
 
@@ -91,6 +96,7 @@ typedef struct {
     int32_t n_oms_alpha_slots;
     const void *oms_alpha;      /* [T][n_oms_alpha_slots] or NULL (= 0)                    */
     const int32_t *oms_alpha_slot; /* [E]                                                  */
+    int32_t schedule;           /* LDPC_SCHED_FLOODING (0) | LDPC_SCHED_LAYERED_REF                */
 } ldpc_decoder_desc;
 
 int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc);

@@ -104,6 +104,86 @@ void oracle_dequantize_f32(const int64_t *codes, int N, const float *thr, int n_
     }
 }
 
+/* RCQMinSumDecoder._decode_layered (rcq_decoder.py:281-350), restated literally -- including the
+ * reference's quirk: `c2v_messages` is re-created (all zero) for every check (:323), so the "subtract
+ * previous C2V messages" step (:300-302) only ever finds the row of the check processed immediately
+ * before; for any code with more than one check that row is a different check and the subtraction is
+ * of zeros: posteriors simply accumulate every check's quantised message, check after check.
+ * One codeword: llr[n] -> bits[n], *iters, *success. */
+static void layered_one(const oracle_graph *g, int T, const float *thresholds, int n_levels, const int32_t *q_of_iter,
+                        const float *llr, int32_t *bits, float *post, int32_t *iters, uint8_t *success,
+                        float *sg, float *mg, float *last_vals)
+{
+    const int n = g->n, m = g->m;
+    for (int j = 0; j < n; ++j) post[j] = llr[j];
+    int last_i = -1, last_dc = 0;
+    for (int it = 0; it < T; ++it) {
+        const float *thr = thresholds + (size_t)q_of_iter[it] * n_levels;
+        for (int i = 0; i < m; ++i) {
+            const int e0 = g->check_ptr[i], dc = g->check_ptr[i + 1] - e0;
+            if (dc == 0) continue;
+            if (i == last_i)            /* the only row c2v_messages still holds */
+                for (int t = 0; t < dc && t < last_dc; ++t) post[g->var_idx[e0 + t]] -= last_vals[t];
+            for (int t = 0; t < dc; ++t) {
+                float in = post[g->var_idx[e0 + t]];
+                sg[t] = in > 0 ? 1.0f : (in < 0 ? -1.0f : 0.0f);
+                mg[t] = fabsf(in);
+            }
+            int k = 0;
+            for (int t = 1; t < dc; ++t) if (mg[t] < mg[k]) k = t;
+            float m1 = mg[k], m2 = m1;
+            if (dc > 1) {
+                m2 = INFINITY;
+                for (int t = 0; t < dc; ++t) if (t != k && mg[t] < m2) m2 = mg[t];
+            }
+            for (int t = 0; t < dc; ++t) {
+                float prod = 1.0f;
+                for (int u = 0; u < dc; ++u) if (u != t) prod = prod * sg[u];
+                float w = prod * ((t == k) ? m2 : m1);                 /* :331 */
+                float mag = fabsf(w);
+                int lvl = 0;
+                for (int q = 0; q < n_levels; ++q) if (mag >= thr[q]) lvl = q;
+                int sb = w < 0.0f;
+                last_vals[t] = (1.0f - 2.0f * (float)sb) * thr[lvl];   /* dequantize(quantize(w)) */
+            }
+            last_i = i; last_dc = dc;
+            for (int t = 0; t < dc; ++t) post[g->var_idx[e0 + t]] += last_vals[t];   /* :338-339 */
+        }
+        int unsat = 0;
+        for (int j = 0; j < n; ++j) bits[j] = post[j] < 0 ? 1 : 0;
+        for (int i = 0; i < m; ++i) {
+            int par = 0;
+            for (int e = g->check_ptr[i]; e < g->check_ptr[i + 1]; ++e) par ^= bits[g->var_idx[e]];
+            unsat += par;
+        }
+        if (unsat == 0) { *iters = it + 1; *success = 1; return; }
+    }
+    for (int j = 0; j < n; ++j) bits[j] = post[j] < 0 ? 1 : 0;
+    *iters = T; *success = 0;
+}
+
+int oracle_decode_layered_f32(const oracle_graph *g, int T, const float *thresholds, int n_levels,
+                              const int32_t *q_of_iter, const float *llr, int B,
+                              int32_t *bits, float *post, int32_t *iters, uint8_t *success)
+{
+    int max_dc = 1;
+    for (int i = 0; i < g->m; ++i) { int d = g->check_ptr[i + 1] - g->check_ptr[i]; if (d > max_dc) max_dc = d; }
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        float *tmp = (float *)malloc(sizeof(float) * (size_t)max_dc * 3);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < B; ++b)
+            layered_one(g, T, thresholds, n_levels, q_of_iter, llr + (size_t)b * g->n, bits + (size_t)b * g->n,
+                        post + (size_t)b * g->n, iters + b, success + b, tmp, tmp + max_dc, tmp + 2 * max_dc);
+        free(tmp);
+    }
+    return 0;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -408,6 +408,35 @@ def gen_offset_and_edge(which):
     return out
 
 
+def gen_layered():
+    """RCQMinSumDecoder(layered=True) (rcq_decoder.py:281-350) on the toy and 48x96 codes"""
+    out = {}
+    for tag in ("toy", "small"):
+        if tag == "toy":
+            code = ref_ldpc.create_test_ldpc_code(); H = code.H
+            llrs = toy_inputs_fp64(64).astype(np.float32); T = 10
+            out["toy_H"] = np.asarray(H).astype(np.uint8)
+        else:
+            H = load_edge_list("small_96_48")
+            code = CachedCode(n=96, k=48, H=H, max_iterations=10)
+            rng = np.random.default_rng(31)
+            llrs = np.concatenate([awgn_llr_decoder_convention(rng, 8, 96, 2.0, np.float32),
+                                   awgn_llr_decoder_convention(rng, 8, 96, 5.0, np.float32),
+                                   special_llrs(rng, 96, 4).astype(np.float32)]); T = 9
+        g = oracle.OracleGraph(H)
+        dec = ref_rcq.RCQMinSumDecoder(code, bc=3, bv=8, quantizer_params=QP, max_iterations=T, layered=True)
+        bits, succ, its = [], [], []
+        for x in llrs:
+            b, s_, i = dec.decode(torch.from_numpy(x.copy()))
+            bits.append(b.numpy().copy()); succ.append(bool(s_)); its.append(int(i))
+        bits, succ, its = np.stack(bits), np.asarray(succ), np.asarray(its, np.int32)
+        ob, op, oi, os_ = oracle.rcq_layered(g, llrs, 3, QP, T)
+        check_equal("layered bits", ob, bits); check_equal("layered iters", oi, its); check_equal("layered success", os_, succ)
+        out.update({f"{tag}_llr": llrs, f"{tag}_bits": bits.astype(np.uint8), f"{tag}_success": succ, f"{tag}_iters": its,
+                    f"{tag}_T": np.int32(T), f"{tag}_oracle_posterior": op})
+    return out
+
+
 def toy_inputs_fp64(count):
     """config 1 inputs: np.random.seed(s); simulate_awgn_channel(zeros(7), 2.0) literally
     (ldpc_decoder.py:286-302), then a block of special vectors, then the flipped sign
@@ -554,6 +583,7 @@ SETS = {
     "ira_wrcq": lambda: gen_ira("wrcq"),
     "toy_offset_edge": lambda: gen_offset_and_edge("toy"),
     "small_offset_edge": lambda: gen_offset_and_edge("small"),
+    "layered_rcq": gen_layered,
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 

@@ -408,6 +408,41 @@ def test_odd_degrees_and_iteration_counts(T, gpu_device, oracle_mod):
     np.testing.assert_array_equal(bits.cpu().numpy(), ob)
 
 
+def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
+    """RCQMinSumDecoder(layered=True): the reference's own outputs (toy, 48x96), then fresh batches on the
+    (1998,1512) code against the oracle in both stop modes"""
+    import codes
+    from ldpc_decoder import LDPCCode
+    from rcq_decoder import RCQMinSumDecoder
+    g = load_golden("layered_rcq")
+    H = g["toy_H"].astype(np.int64)
+    cases = [("toy", LDPCCode(n=7, k=4, H=H, max_iterations=10)), ("small", codes.load_code("small_96_48", 10))]
+    for tag, code in cases:
+        dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=int(g[f"{tag}_T"]), layered=True)
+        llr = torch.from_numpy(g[f"{tag}_llr"])
+        bits, succ, iters = dec.decode(llr.to(gpu_device))
+        np.testing.assert_array_equal(iters.cpu().numpy(), g[f"{tag}_iters"])
+        np.testing.assert_array_equal(succ.cpu().numpy(), g[f"{tag}_success"])
+        np.testing.assert_array_equal(bits.cpu().numpy(), g[f"{tag}_bits"].astype(np.int32))
+        b1, s1, i1 = dec.decode(llr[3])
+        assert isinstance(s1, bool) and (s1, i1) == (bool(g[f"{tag}_success"][3]), int(g[f"{tag}_iters"][3]))
+        np.testing.assert_array_equal(b1.numpy(), g[f"{tag}_bits"][3].astype(np.int32))
+    code = codes.load_code("ira_1998_1512", 10)
+    tg = code.tanner_graph()
+    og = oracle_mod.OracleGraph(n=tg.n, check_ptr=tg.check_ptr, var_idx=tg.var_idx)
+    rng = np.random.default_rng(9)
+    llr = np.concatenate([awgn(rng, 100, tg.n, 2.0), awgn(rng, 100, tg.n, 6.5)])[rng.permutation(200)]
+    dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=10, layered=True)
+    bits, succ, iters = dec.decode(torch.from_numpy(llr).to(gpu_device))
+    ob, op, oi, os_ = oracle_mod.rcq_layered(og, llr, 3, QP, 10)
+    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    res = dec._engine.decode(torch.from_numpy(llr).to(gpu_device), early_stop=True)
+    np.testing.assert_array_equal(res.posterior.cpu().numpy(), op)          # latched posteriors, value-equal
+    assert len(np.unique(oi)) >= 2                                          # early stop was exercised
+
+
 def sparse_odd_code():
     """14x40 sparse code that QUALIFIES for the LDS-resident engine (dc <= 32, dv <= 8) and still has a
     degree-1 check, an empty check, an isolated variable and a degree-1 variable"""
@@ -486,8 +521,10 @@ def test_error_behaviour(gpu_device):
         Neural2DMinSumDecoder(code, weight_sharing_type=5, max_iterations=3)      # neural_2d_decoder.py:82
     with pytest.raises(ValueError):
         BasicMinSumDecoder(code).decode(np.zeros(6))
-    with pytest.raises(NotImplementedError):
-        RCQMinSumDecoder(code, 3, 8, QP, 10, layered=True).decode(torch.zeros(7))
+    from ldpc_decoder import LDPCCode
+    one_check = LDPCCode(n=4, k=3, H=np.ones((1, 4), dtype=int), max_iterations=3)
+    with pytest.raises(NotImplementedError):         # the only case where the reference's layered subtraction is real
+        RCQMinSumDecoder(one_check, 3, 8, QP, 3, layered=True).decode(torch.zeros(4))
     with pytest.raises(TypeError):
         RCQMinSumDecoder(code, 3, 8, QP, 10).decode(np.zeros(7))
     # empty batch

@@ -168,6 +168,18 @@ def test_offset_and_edge_weight_golden(name, oracle_mod):
         np.testing.assert_array_equal(post, sub["posterior"])
 
 
+def test_layered_rcq_golden(oracle_mod):
+    """RCQMinSumDecoder(layered=True) as the reference executes it (rcq_decoder.py:281-350)"""
+    g = load_golden("layered_rcq")
+    for tag, og in (("toy", oracle_mod.OracleGraph(g["toy_H"].astype(np.int64))),
+                    ("small", graph_of(oracle_mod, {"graph": "small_96_48"}))):
+        bits, post, iters, succ = oracle_mod.rcq_layered(og, g[f"{tag}_llr"], 3, [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)],
+                                                         int(g[f"{tag}_T"]))
+        np.testing.assert_array_equal(bits, g[f"{tag}_bits"])
+        np.testing.assert_array_equal(iters, g[f"{tag}_iters"])
+        np.testing.assert_array_equal(succ, g[f"{tag}_success"])
+
+
 # ------------------------------------------------------------------ oracle self-consistency
 def test_fixed_iteration_mode_and_threads(oracle_mod):
     """early_stop=False runs T iterations; success = final syndrome; threads do not change results"""
