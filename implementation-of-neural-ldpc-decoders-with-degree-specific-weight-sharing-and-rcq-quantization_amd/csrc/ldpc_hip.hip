@@ -90,6 +90,7 @@ struct ldpc_decoder {
     int mode = 0;                  // LDPC_MODE_*
     bool res_ok = false;
     int res_G = 0, res_NT = 0;
+    bool unit_alpha = false, rcq_zero0 = false;   // table properties the resident kernel exploits
     size_t res_lds = 0;
     ResidentPlan res{};
     std::vector<void *> res_bufs;  // device allocations owned by the plan
@@ -321,6 +322,22 @@ int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool 
 }
 
 
+// alpha table identically 1.0f / every quantiser's tau_0 == 0: exact shortcuts in the resident kernel
+void resident_table_flags(ldpc_decoder *d, const void *alpha_host, const float *thr_host)
+{
+    if (alpha_host && d->dtype == LDPC_F32) {
+        const float *a = (const float *)alpha_host;
+        bool unit = true;
+        for (size_t k = 0; k < (size_t)std::max(d->T, 0) * d->n_alpha; ++k) unit = unit && a[k] == 1.0f;
+        d->unit_alpha = unit;
+    }
+    if (thr_host) {
+        bool z = true;
+        for (int q = 0; q < d->n_quant; ++q) z = z && thr_host[(size_t)q * d->n_levels] == 0.0f;
+        d->rcq_zero0 = z;
+    }
+}
+
 // ---- LDS-resident engine: plan (host) ---------------------------------------------------------
 constexpr size_t kLdsBytes = 160 * 1024;          // LDS per CU; one workgroup may take all of it
 
@@ -425,21 +442,35 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     d->res_ok = false;
     if (d->dtype != LDPC_F32 || g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
     const int n = g->n, m = g->m;
-    const long long S = (long long)g->max_dc * m;
-    if (S > 65535 || n > 65535 || d->n_beta > 65535 || d->n_alpha >= (1 << 24) || d->n_oms_alpha > 65535) return LDPC_OK;
-    if (!resident_fits(d, S, 1, 1)) return LDPC_OK;
+    if (n > 65535 || d->n_beta > 65535 || d->n_alpha >= (1 << 24) || d->n_oms_alpha > 65535) return LDPC_OK;
 
-    // geometry: G codewords per workgroup, NT threads.  Two 512-thread workgroups per CU (G = 2,
-    // ds_read/write_b64) let one workgroup's barrier wait overlap the other's phase -- measured best on
-    // the (1998,1512) code; larger codes fall back to one workgroup per CU.  LDPC_RESIDENT_G / _NT
-    // override for tuning.
-    int G = 0, NT = 0;
-    const char *eg = getenv("LDPC_RESIDENT_G"), *en = getenv("LDPC_RESIDENT_NT");
-    if (eg) G = atoi(eg);
-    if (en) NT = atoi(en);
-    if (!((G == 1 || G == 2 || G == 4) && resident_fits(d, S, G, 1))) G = resident_fits(d, S, 2, 1) ? 2 : 1;
-    int blocks = 1;
-    while (blocks < 8 && resident_fits(d, S, G, blocks + 1)) ++blocks;
+    // geometry: G codewords per workgroup, NT threads, and the row stride of the slot layout.
+    // Two 512-thread workgroups per CU (G = 2, ds_read/write_b64) let one workgroup's barrier wait overlap
+    // the other's phase -- measured best on the (1998,1512) code; larger codes fall back to one workgroup
+    // per CU or G = 1.  A row stride of 512 slots (instead of m) lets LDS instructions carry t*stride as an
+    // immediate offset; it is taken when it costs neither G nor workgroups per CU.
+    // LDPC_RESIDENT_G / _NT override for tuning.
+    auto geometry = [&](int stride, int &G_out, int &blocks_out) {
+        const long long S_ = (long long)g->max_dc * stride;
+        if (S_ > 65535 || !resident_fits(d, S_, 1, 1)) return false;
+        int G_ = 0;
+        const char *eg = getenv("LDPC_RESIDENT_G");
+        if (eg) G_ = atoi(eg);
+        if (!((G_ == 1 || G_ == 2) && resident_fits(d, S_, G_, 1))) G_ = resident_fits(d, S_, 2, 1) ? 2 : 1;
+        int b_ = 1;
+        while (b_ < 8 && resident_fits(d, S_, G_, b_ + 1)) ++b_;
+        G_out = G_; blocks_out = b_;
+        return true;
+    };
+    int G = 0, blocks = 0, mstride = m;
+    if (!geometry(m, G, blocks)) return LDPC_OK;
+    if (m <= 512) {
+        int G5 = 0, b5 = 0;
+        if (geometry(512, G5, b5) && G5 == G && std::min(b5, 2) == std::min(blocks, 2)) { mstride = 512; blocks = b5; }
+    }
+    const long long S = (long long)g->max_dc * mstride;
+    int NT = 0;
+    { const char *en = getenv("LDPC_RESIDENT_NT"); if (en) NT = atoi(en); }
     if (NT < 64 || NT > 1024 || NT % 64) NT = blocks >= 2 ? 512 : 1024;
 
     std::vector<int> perm_c(m), perm_v(n), pos_c(m), pos_v(n);
@@ -455,7 +486,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
         for (int j = 0; j < n; ++j)
             for (int k = 0; k < dv_of(j); ++k) {
                 const int e = g->h_csc[g->h_var_ptr[j] + k], i = g->h_check_of_edge[e];
-                vs[j].push_back((e - g->h_check_ptr[i]) * m + pos_c[i]);
+                vs[j].push_back((e - g->h_check_ptr[i]) * mstride + pos_c[i]);
             }
         optimise_lane_order(perm_v, vs, G);
     }
@@ -464,14 +495,14 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     std::vector<uint8_t> dc_s(m);
     std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0), inv(n);
     std::vector<uint32_t> vmeta(n);
-    std::vector<uint4> vslot8(n);
+    std::vector<uint4> vslot_lo(n), vslot_hi(n);
     std::vector<int> slot_of_edge(g->E);
     bool per_check = true;
     for (int p = 0; p < m; ++p) {
         const int i = perm_c[p], e0 = g->h_check_ptr[i], dc = dc_of(i);
         dc_s[p] = (uint8_t)dc;
         for (int t = 0; t < dc; ++t) {
-            const int e = e0 + t, slot = t * m + p;
+            const int e = e0 + t, slot = t * mstride + p;
             slot_of_edge[e] = slot;
             cvar[slot] = (uint16_t)pos_v[g->h_var_idx[e]];
             bslot[slot] = (uint16_t)desc->beta_slot[e];
@@ -486,18 +517,20 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
         inv[j] = (uint16_t)q;
         uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < dv; ++k) off[k] = (uint32_t)slot_of_edge[g->h_csc[s0 + k]] * G * 4;
-        vslot8[q] = make_uint4(off[0] | off[1] << 16, off[2] | off[3] << 16, off[4] | off[5] << 16, off[6] | off[7] << 16);
+        vslot_lo[q] = make_uint4(off[0], off[1], off[2], off[3]);
+        vslot_hi[q] = make_uint4(off[4], off[5], off[6], off[7]);
     }
     ResidentPlan &pl = d->res;
     pl = ResidentPlan{};
-    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv;
+    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv; pl.mstride = mstride;
     int rc = plan_upload(d, &pl.dc_s, dc_s);
     if (!rc) rc = plan_upload(d, &pl.cvar, cvar);
     if (!rc) rc = plan_upload(d, &pl.bslot, bslot);
     if (!rc && per_check) rc = plan_upload(d, &pl.bslot_c, bslot_c);
     if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha) rc = plan_upload(d, &pl.oaslot, oaslot);
     if (!rc) rc = plan_upload(d, &pl.vmeta, vmeta);
-    if (!rc) rc = plan_upload(d, &pl.vslot8, vslot8);
+    if (!rc) rc = plan_upload(d, &pl.vslot_lo, vslot_lo);
+    if (!rc) rc = plan_upload(d, &pl.vslot_hi, vslot_hi);
     if (!rc) rc = plan_upload(d, &pl.inv_perm_v, inv);
     if (rc) return rc;
     d->res_G = G; d->res_NT = NT;
@@ -510,17 +543,23 @@ template <int G>
 int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
 {
     const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
-    const size_t lds = d->res_lds;
-#define LDPC_RES(FORM, NL)                                                                               \
+    size_t lds = d->res_lds;
+    { const char *pad = getenv("LDPC_RES_LDS_PAD"); if (pad && atoi(pad) > 0) lds = std::min<size_t>(lds + atoi(pad), 160 * 1024); }  // occupancy experiments
+#define LDPC_RES_MS(FORM, NL, MS)                                                                        \
     do {                                                                                                 \
-        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true, NL> : resident_decode<G, FORM, false, NL>; \
+        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true, NL, MS> : resident_decode<G, FORM, false, NL, MS>; \
         HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
+    } while (0)
+#define LDPC_RES(FORM, NL)                                                                               \
+    do {                                                                                                 \
+        if (d->res.mstride == 512) LDPC_RES_MS(FORM, NL, 512); else LDPC_RES_MS(FORM, NL, 0);            \
     } while (0)
     if (d->form == LDPC_C2V_NMS) LDPC_RES(FORM_NMS, 0);
     else if (d->form == LDPC_C2V_OMS) LDPC_RES(FORM_OMS, 0);
     else if (d->n_levels == 4) LDPC_RES(FORM_RCQ, 4);       // bc = 3, the paper's and the benchmark's quantiser
     else LDPC_RES(FORM_RCQ, 0);
+#undef LDPC_RES_MS
 #undef LDPC_RES
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
@@ -691,6 +730,7 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
         rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
         if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
     }
+    resident_table_flags(d, desc->alpha, d->form == LDPC_C2V_RCQ ? desc->thresholds : nullptr);
     if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
     if (rc) {
         ldpc_decoder_destroy(d);
@@ -730,7 +770,10 @@ int ldpc_decoder_set_weights(ldpc_decoder *d, const void *beta, const void *alph
     hipStream_t s = (hipStream_t)stream;
     const size_t es = d->elem(), rows = (size_t)d->T;
     if (beta) HIP_TRY(hipMemcpyAsync(d->beta, beta, rows * d->n_beta * es, hipMemcpyHostToDevice, s));
-    if (alpha) HIP_TRY(hipMemcpyAsync(d->alpha, alpha, rows * d->n_alpha * es, hipMemcpyHostToDevice, s));
+    if (alpha) {
+        HIP_TRY(hipMemcpyAsync(d->alpha, alpha, rows * d->n_alpha * es, hipMemcpyHostToDevice, s));
+        resident_table_flags(d, alpha, nullptr);
+    }
     if (oms_alpha) {
         if (!d->oms_alpha) return fail(LDPC_ERR_ARG, "decoder was created without oms_alpha");
         HIP_TRY(hipMemcpyAsync(d->oms_alpha, oms_alpha, rows * d->n_oms_alpha * es, hipMemcpyHostToDevice, s));
@@ -778,11 +821,11 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
         a.packed = packed_bits;
         { const char *dbg = getenv("LDPC_RES_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
         a.alpha_in_lds = resident_alpha_floats(d) > 0;
+        a.unit_alpha = d->unit_alpha; a.rcq_zero0 = d->rcq_zero0;
         hipStream_t rs = (hipStream_t)stream;
         switch (d->res_G) {
         case 1: return launch_resident<1>(d, a, rs);
-        case 2: return launch_resident<2>(d, a, rs);
-        default: return launch_resident<4>(d, a, rs);
+        default: return launch_resident<2>(d, a, rs);
         }
     }
     const Workspace w = carve(d, batch, workspace);

@@ -34,6 +34,9 @@ namespace ldpc {
 
 struct ResidentPlan {
     int n, m, S, max_dc, max_dv;
+    int mstride;                  // slots between consecutive edges of a check: slot(p,t) = t*mstride + p
+                                  // (512 when m <= 512 so that LDS instructions can carry t*stride as an
+                                  //  immediate offset; else m)
     const uint8_t *dc_s;          // [m]          degree of the check at sorted position p
     const uint16_t *cvar;         // [max_dc*m]   sorted position of the variable of edge (p,t)
     const uint16_t *bslot;        // [max_dc*m]   beta table column of edge (p,t)
@@ -41,8 +44,8 @@ struct ResidentPlan {
                                   //              sharing types 2-4) -> one table read per check
     const uint16_t *oaslot;       // [max_dc*m]   OMS alpha column (or null)
     const uint32_t *vmeta;        // [n]          degree | alpha column << 8 of sorted variable q
-    const uint4 *vslot8;          // [n]          8 x u16: LDS byte offset of the k-th (ascending
-                                  //              check) edge's slot, = slot * G * 4
+    const uint4 *vslot_lo;        // [n]          LDS byte offsets (= slot * G * 4) of edges k = 0..3 of q
+    const uint4 *vslot_hi;        // [n]          ... of edges k = 4..7 (read only when max_dv > 4)
     const uint16_t *inv_perm_v;   // [n]          sorted position of original variable j
 };
 
@@ -56,6 +59,8 @@ struct ResidentArgs {
     const float *thr; int n_levels; const int *q_of_iter;
     int *bits; float *posterior; int *iterations; uint8_t *success; uint8_t *packed;
     int alpha_in_lds;             // T * n_alpha floats staged in LDS
+    int unit_alpha;               // every alpha == 1.0f (Basic, RCQ, sharing types 1/3): the multiply is skipped
+    int rcq_zero0;                // every quantiser has tau_0 == 0 (true for gamma > 0): per-check quantisation
     int debug_skip;               // phase-timing probes, compiled in only with -DLDPC_RESIDENT_PROBES (tools/resident_probe*.sh)
 };
 
@@ -79,45 +84,106 @@ __device__ __forceinline__ bool wave_uniform(int v, int &vw)
 //           |x| == min1 -- on a tie min2 == min1, so which tied edge "is" the arg-min is
 //           value-irrelevant, exactly as with the reference's first-index argmin -- and the sign of
 //           the product of the OTHER signs is bit 31 of (signs ^ x).
-template <int G, int FORM, bool BPC, bool UNI, int NL>
+// quantise-and-reconstruct magnitude: tau[last q with mag >= tau_q], default tau_0; the q = 0
+// comparison can never change the outcome and is left out (any threshold order, NaN included)
+template <int NL>
+__device__ __forceinline__ float res_quant_rec(float mag, const float (&th)[8], const float *__restrict__ thr, int n_levels)
+{
+    float rec = (n_levels <= 8) ? th[0] : thr[0];
+    if constexpr (NL > 0) {                                   // compile-time level count (bc = 3: 4)
+#pragma unroll
+        for (int q = 1; q < NL; ++q) rec = (mag >= th[q]) ? th[q] : rec;
+    } else if (n_levels <= 8) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;   // NaN padding never matches
+    } else {
+        for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+    }
+    return rec;
+}
+
+template <int G, int FORM, bool BPC, bool UNI, int NL, int MS>
 __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned char *smem, int p, int dc, int dcw,
                                                float b_check, const float *__restrict__ beta_row,
                                                const float *__restrict__ oa_row, const float (&th)[8],
-                                               const float *__restrict__ thr, int n_levels)
+                                               const float *__restrict__ thr, int n_levels, bool rcq_zero0)
 {
     using P = Pack<float, G>;
     constexpr int kEl = G * 4;
     const int trip = UNI ? dcw : dc;
-    const unsigned stride = (unsigned)pl.m * kEl;
+    const unsigned stride = (MS > 0 ? (unsigned)MS : (unsigned)pl.mstride) * kEl;   // compile-time when MS > 0
+    const unsigned base = (unsigned)p * kEl;
     float m1[G], m2[G];
     uint32_t sacc[G];
     unsigned nz[G];
+    float ninf = -inf_of<float>();
+    asm volatile("" : "+v"(ninf));                    // opaque to constant folding (see below)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         m1[g] = inf_of<float>(); m2[g] = inf_of<float>(); sacc[g] = 0; nz[g] = 0;
     }
-    unsigned addr = (unsigned)p * kEl;
 #pragma unroll 4
     for (int t = 0; t < trip; ++t) {
-        const P v = *reinterpret_cast<const P *>(smem + addr);
-        addr += stride;
+        const P v = *reinterpret_cast<const P *>(smem + base + t * stride);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float a = __builtin_fabsf(v.x[g]);
             sacc[g] ^= __float_as_uint(v.x[g]);
             if (FORM == FORM_OMS) nz[g] += (a == 0.0f) ? 1u : 0u;
             m2[g] = __builtin_amdgcn_fmed3f(a, m1[g], m2[g]);
-            m1[g] = __builtin_amdgcn_fmed3f(a, m1[g], -inf_of<float>());   // = min(a, min1), no canonicalise ops
+            m1[g] = __builtin_amdgcn_fmed3f(a, m1[g], ninf);               // = min(a, min1) as ONE v_med3 (a
+                                                                           // literal -inf is folded into
+                                                                           // canonicalise + v_min: 3 ops)
         }
     }
     if (trip == 1) {
 #pragma unroll
         for (int g = 0; g < G; ++g) m2[g] = m1[g];     // "min2_val = min_val" for a degree-1 check
     }
-    addr = (unsigned)p * kEl;
+
+    if (BPC && (FORM == FORM_NMS || (FORM == FORM_RCQ && rcq_zero0))) {
+        // One beta per check: only two outgoing magnitudes exist per codeword, so scaling (and for RCQ the
+        // whole quantise-reconstruct) is done twice per check instead of once per edge.  Per edge remains:
+        // pick by |x| == min1, then xor in the edge's own sign bit (the parity of all signs is pre-folded).
+        uint32_t o1[G], o2[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float w1 = b_check * m1[g], w2 = b_check * m2[g];
+            if (FORM == FORM_RCQ) {
+                // value = (1 - 2*(w < 0)) * tau[level(|w|)]; with tau_0 == 0 a zero magnitude reconstructs to
+                // +-0, so applying the edge sign afterwards is value-identical to the reference's order
+                const float r1 = res_quant_rec<NL>(__builtin_fabsf(w1), th, thr, n_levels);
+                const float r2 = res_quant_rec<NL>(__builtin_fabsf(w2), th, thr, n_levels);
+                w1 = flip_sign<float>(r1, (w1 < 0.0f) ? 1u : 0u);
+                w2 = flip_sign<float>(r2, (w2 < 0.0f) ? 1u : 0u);
+            }
+            const uint32_t par = sacc[g] & 0x80000000u;
+            o1[g] = __float_as_uint(w1) ^ par;
+            o2[g] = __float_as_uint(w2) ^ par;
+            // keep the two per-check values materialised: without the barrier the optimiser sinks the
+            // multiply (and the quantiser) back behind the per-edge select
+            asm volatile("" : "+v"(o1[g]), "+v"(o2[g]));
+        }
+#pragma unroll 4
+        for (int t = 0; t < trip; ++t) {
+            const unsigned addr = base + t * stride;
+            const P v = *reinterpret_cast<const P *>(smem + addr);
+            P o;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t sel = (__builtin_fabsf(v.x[g]) == m1[g]) ? o2[g] : o1[g];
+                o.x[g] = __uint_as_float(sel ^ (__float_as_uint(v.x[g]) & 0x80000000u));
+            }
+            *reinterpret_cast<P *>(smem + addr) = o;
+        }
+        return;
+    }
+
     int slot = p;
+    const int sstride = MS > 0 ? MS : pl.mstride;
 #pragma unroll 2
     for (int t = 0; t < trip; ++t) {
+        const unsigned addr = base + t * stride;
         const float b = BPC ? b_check : beta_row[pl.bslot[slot]];
         float oa = 0.0f;
         if (FORM == FORM_OMS && oa_row) oa = oa_row[pl.oaslot[slot]];
@@ -140,35 +206,22 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
             } else {
                 // quantise + reconstruct in one go: value = (1 - 2*sign_bit) * tau[level]
                 const float w = __uint_as_float(__float_as_uint(b * raw) ^ sflip);
-                const float mag = __builtin_fabsf(w);
-                // level = last q with mag >= tau_q, default 0 -- so the q = 0 comparison can never
-                // change the outcome and is left out (any threshold order, NaN included)
-                float rec = (n_levels <= 8) ? th[0] : thr[0];
-                if constexpr (NL > 0) {                                   // compile-time level count (bc = 3: 4)
-#pragma unroll
-                    for (int q = 1; q < NL; ++q) rec = (mag >= th[q]) ? th[q] : rec;
-                } else if (n_levels <= 8) {
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) rec = (mag >= th[q]) ? th[q] : rec;   // NaN padding never matches
-                } else {
-                    for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
-                }
+                const float rec = res_quant_rec<NL>(__builtin_fabsf(w), th, thr, n_levels);
                 o.x[g] = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
             }
         }
         *reinterpret_cast<P *>(smem + addr) = o;
-        addr += stride;
-        slot += pl.m;
+        slot += sstride;
     }
 }
 
 // `dc_pre` / `b_pre` are the first round's degree and per-check beta, fetched by the caller ahead of
 // the barrier so their global-memory latency is off the critical path.
-template <int G, int FORM, bool BPC, int NL>
+template <int G, int FORM, bool BPC, int NL, int MS>
 __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned char *smem,
                                                 const float *__restrict__ beta_row,
                                                 const float *__restrict__ oa_row,
-                                                const float *__restrict__ thr, int n_levels,
+                                                const float *__restrict__ thr, int n_levels, bool rcq_zero0,
                                                 int dc_pre, float b_pre, int tid, int nt)
 {
     float th[8];
@@ -185,44 +238,45 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
         }
         int dcw;
         if (wave_uniform(dc, dcw))
-            res_check_body<G, FORM, BPC, true, NL>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
+            res_check_body<G, FORM, BPC, true, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
         else
-            res_check_body<G, FORM, BPC, false, NL>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels);
+            res_check_body<G, FORM, BPC, false, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
     }
 }
 
 // ---- variable phase, lane = variable ----------------------------------------------------------
 // MODE 0: v2c = llr + alpha * sum(others), scattered back in place
+// MODE 2: the same with alpha == 1 everywhere (1.0f * x == x exactly, the multiply is skipped)
 // MODE 1: posterior -> hard-decision byte bits_s[q]; components in `emask` also overwrite their
 //         (dead) LLR slot with the posterior so the output pass can read it in original order
 template <int G, int DV, int MODE>
 __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restrict__ llr_s,
-                                             uint8_t *__restrict__ bits_s, int q, const uint4 &s8,
+                                             uint8_t *__restrict__ bits_s, int q, const uint4 &slo, const uint4 &shi,
                                              float a, unsigned emask)
 {
     using P = Pack<float, G>;
     P *L = reinterpret_cast<P *>(llr_s);
-    const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,
-                             s8.z & 0xffffu, s8.z >> 16, s8.w & 0xffffu, s8.w >> 16};
+    const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
     P x[DV > 0 ? DV : 1];
 #pragma unroll
     for (int k = 0; k < DV; ++k) x[k] = *reinterpret_cast<const P *>(smem + off[k]);
     P l = L[q];
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 2) {
         P out[DV > 0 ? DV : 1];
+        auto v2c = [&](float llr, float sum) { return MODE == 2 ? llr + sum : llr + a * sum; };
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float xs[DV > 0 ? DV : 1];
 #pragma unroll
             for (int k = 0; k < DV; ++k) xs[k] = x[k].x[g];
-            if constexpr (DV >= 1) out[0].x[g] = l.x[g] + a * sum_ct<DV - 1, 0, 0, float>(xs);
-            if constexpr (DV >= 2) out[1].x[g] = l.x[g] + a * sum_ct<DV - 1, 1, 0, float>(xs);
-            if constexpr (DV >= 3) out[2].x[g] = l.x[g] + a * sum_ct<DV - 1, 2, 0, float>(xs);
-            if constexpr (DV >= 4) out[3].x[g] = l.x[g] + a * sum_ct<DV - 1, 3, 0, float>(xs);
-            if constexpr (DV >= 5) out[4].x[g] = l.x[g] + a * sum_ct<DV - 1, 4, 0, float>(xs);
-            if constexpr (DV >= 6) out[5].x[g] = l.x[g] + a * sum_ct<DV - 1, 5, 0, float>(xs);
-            if constexpr (DV >= 7) out[6].x[g] = l.x[g] + a * sum_ct<DV - 1, 6, 0, float>(xs);
-            if constexpr (DV >= 8) out[7].x[g] = l.x[g] + a * sum_ct<DV - 1, 7, 0, float>(xs);
+            if constexpr (DV >= 1) out[0].x[g] = v2c(l.x[g], sum_ct<DV - 1, 0, 0, float>(xs));
+            if constexpr (DV >= 2) out[1].x[g] = v2c(l.x[g], sum_ct<DV - 1, 1, 0, float>(xs));
+            if constexpr (DV >= 3) out[2].x[g] = v2c(l.x[g], sum_ct<DV - 1, 2, 0, float>(xs));
+            if constexpr (DV >= 4) out[3].x[g] = v2c(l.x[g], sum_ct<DV - 1, 3, 0, float>(xs));
+            if constexpr (DV >= 5) out[4].x[g] = v2c(l.x[g], sum_ct<DV - 1, 4, 0, float>(xs));
+            if constexpr (DV >= 6) out[5].x[g] = v2c(l.x[g], sum_ct<DV - 1, 5, 0, float>(xs));
+            if constexpr (DV >= 7) out[6].x[g] = v2c(l.x[g], sum_ct<DV - 1, 6, 0, float>(xs));
+            if constexpr (DV >= 8) out[7].x[g] = v2c(l.x[g], sum_ct<DV - 1, 7, 0, float>(xs));
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) *reinterpret_cast<P *>(smem + off[k]) = out[k];
@@ -245,10 +299,10 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
 
 template <int G, int MODE>
 __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__restrict__ llr_s,
-                                                 uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &s8,
-                                                 float a, unsigned emask)
+                                                 uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &slo,
+                                                 const uint4 &shi, float a, unsigned emask)
 {
-#define LDPC_RV(D) case D: res_var_body<G, D, MODE>(smem, llr_s, bits_s, q, s8, a, emask); break;
+#define LDPC_RV(D) case D: res_var_body<G, D, MODE>(smem, llr_s, bits_s, q, slo, shi, a, emask); break;
     switch (dv) {
         LDPC_RV(0) LDPC_RV(1) LDPC_RV(2) LDPC_RV(3) LDPC_RV(4) LDPC_RV(5) LDPC_RV(6) LDPC_RV(7) LDPC_RV(8)
     default: break;   // host admits only max_dv <= 8 to this engine
@@ -256,8 +310,8 @@ __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__r
 #undef LDPC_RV
 }
 
-// Index data (degree, alpha column, the 8 slot offsets) of the NEXT variable of a lane is fetched
-// from global memory (L1/L2 resident, shared by every workgroup) while the current one is processed.
+// Index data (degree, alpha column, the slot offsets) of the NEXT variable of a lane is fetched from
+// global memory (L1/L2 resident, shared by every workgroup) while the current one is processed.
 template <int G, int MODE>
 __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned char *smem,
                                               float *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
@@ -266,24 +320,34 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
                                               int tid, int nt)
 {
     const int n = pl.n;
+    const bool wide = pl.max_dv > 4;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     int q = tid;
     unsigned meta = 0;
-    uint4 s8 = make_uint4(0, 0, 0, 0);
-    if (q < n) { meta = pl.vmeta[q]; s8 = pl.vslot8[q]; }
+    uint4 slo = zero4, shi = zero4;
+    if (q < n) {
+        meta = pl.vmeta[q];
+        slo = pl.vslot_lo[q];
+        if (wide) shi = pl.vslot_hi[q];
+    }
     while (q < n) {
         const int qn = q + nt;
         unsigned metan = 0;
-        uint4 s8n = make_uint4(0, 0, 0, 0);
-        if (qn < n) { metan = pl.vmeta[qn]; s8n = pl.vslot8[qn]; }
+        uint4 slon = zero4, shin = zero4;
+        if (qn < n) {
+            metan = pl.vmeta[qn];
+            slon = pl.vslot_lo[qn];
+            if (wide) shin = pl.vslot_hi[qn];
+        }
         const int dv = (int)(meta & 0xffu);
         float a = 0.0f;                                                  // LDS copy of the table when small
         if (MODE == 0) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
         int dvw;
         if (wave_uniform(dv, dvw))
-            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, s8, a, emask);      // scalar branch
+            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);      // scalar branch
         else
-            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dv, s8, a, emask);       // class-boundary wave
-        q = qn; meta = metan; s8 = s8n;
+            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask);       // class-boundary wave
+        q = qn; meta = metan; slo = slon; shi = shin;
     }
 }
 
@@ -299,9 +363,9 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
         unsigned x = 0;
         if (wave_uniform(dc, dcw)) {
 #pragma unroll 8
-            for (int t = 0; t < dcw; ++t) x ^= bits_s[pl.cvar[t * pl.m + p]];
+            for (int t = 0; t < dcw; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
         } else {
-            for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.m + p]];
+            for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
         }
         acc |= x;
     }
@@ -346,7 +410,7 @@ __host__ __device__ inline size_t res_off_bits(int S, int n, int G, int n_alpha_
 __host__ __device__ inline size_t res_off_flag(int S, int n, int G, int n_alpha_lds) { return (res_off_bits(S, n, G, n_alpha_lds) + n + 3) / 4 * 4; }
 __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
 
-template <int G, int FORM, bool BPC, int NL>
+template <int G, int FORM, bool BPC, int NL, int MS>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
@@ -377,9 +441,9 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const P *L = reinterpret_cast<const P *>(llr_s);
         for (int q = tid; q < n && !LDPC_PROBE(a, 32); q += nt) {
             const int dv = (int)(pl.vmeta[q] & 0xffu);
-            const uint4 s8 = pl.vslot8[q];
-            const unsigned off[8] = {s8.x & 0xffffu, s8.x >> 16, s8.y & 0xffffu, s8.y >> 16,
-                                     s8.z & 0xffffu, s8.z >> 16, s8.w & 0xffffu, s8.w >> 16};
+            const uint4 slo = pl.vslot_lo[q];
+            const uint4 shi = pl.max_dv > 4 ? pl.vslot_hi[q] : make_uint4(0, 0, 0, 0);
+            const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
             P l = L[q];
             if (a.T == 0) {
 #pragma unroll
@@ -407,7 +471,8 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const float *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
         const float *alpha_glb = a.alpha + (size_t)it * a.n_alpha;
         if (!LDPC_PROBE(a, 1))
-            res_check_phase<G, FORM, BPC, NL>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, dc_pre, b_pre, tid, nt);
+            res_check_phase<G, FORM, BPC, NL, MS>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, a.rcq_zero0 != 0,
+                                                  dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
         __syncthreads();
@@ -432,7 +497,8 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             }
         }
         if (it != a.T - 1 && !LDPC_PROBE(a, 2)) {
-            res_var_phase<G, 0>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
+            if (a.unit_alpha) res_var_phase<G, 2>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
+            else res_var_phase<G, 0>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
         }
     }

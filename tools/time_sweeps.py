@@ -17,9 +17,18 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    gname, T, B0, _ = bench.WORKLOADS[a.workload]
-    B = a.batch or B0
-    eng, dec, code = bench.build_decoder(a.workload, dev)
+    if a.workload == "basic_small":           # 2/3-scale copy of the (1998,1512) code: fits 3 workgroups per CU
+        import codes
+        from ldpc_decoder import BasicMinSumDecoder, LDPCCode
+        g0 = codes.generate_ira_code(n=1332, m=324, info_degrees={8: 144, 3: 864}, check_degrees=None, seed=1332)
+        code = LDPCCode.from_graph(g0, k=1008, max_iterations=10)
+        dec = BasicMinSumDecoder(code, 0.7)
+        eng = dec._engine(torch.float32, dev)
+        T, B = 10, a.batch or 65536
+    else:
+        gname, T, B0, _ = bench.WORKLOADS[a.workload]
+        B = a.batch or B0
+        eng, dec, code = bench.build_decoder(a.workload, dev)
     llr = bench.make_llr(B, code.n, 2.0, 1234, dev)
     for _ in range(2):
         eng.decode(llr, early_stop=False, want_posterior=False)
@@ -33,6 +42,7 @@ def main():
     out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5,
            "engine": eng.info()}
     out["Mcw_s"] = B / out["decode_ms"] / 1e3
+    out["ns_per_edge_iter"] = out["decode_ms"] * 1e6 / (B * T * code.tanner_graph().E)
     if eng.info()["engine"] != "stream":
         print(json.dumps(out))
         return
@@ -46,6 +56,7 @@ def main():
         e1.record(); e1.synchronize()
         out[name] = e0.elapsed_time(e1) / a.reps
     g = code.tanner_graph()
+    out["E"] = g.E
     rcq = a.workload in ("rcq", "wrcq_dvbs2")
     out["cn_GBs"] = (5 if rcq else 8) * g.E * B / out["cn_ms"] / 1e6
     out["vn_GBs"] = ((5 if rcq else 8) * g.E + 4 * g.n) * B / out["vn_ms"] / 1e6
