@@ -72,6 +72,32 @@ constexpr int kResAlphaMax = 1024;   // floats of alpha table kept in LDS
 #define LDPC_PROBE(a, bit) 0
 #endif
 
+// LDS access by byte offset.  The dynamic LDS block is this kernel's only LDS object (no static
+// __shared__), so it starts at LDS address 0 and a message slot's byte offset IS its LDS address:
+// addressing through an address-space-3 pointer built from the offset avoids the "+ base" VALU add
+// that the generic-pointer form leaves on every access.  resident_decode traps if a static LDS
+// allocation ever appears in front of the dynamic block.
+template <typename X>
+__device__ __forceinline__ X lds_load(unsigned byte_off)
+{
+    constexpr int N = sizeof(X) / sizeof(float);
+    typedef float VT __attribute__((ext_vector_type(N)));
+    using LP = __attribute__((address_space(3))) const VT *;
+    union { VT v; X k; } u;
+    u.v = *(LP)(size_t)byte_off;
+    return u.k;
+}
+template <typename X>
+__device__ __forceinline__ void lds_store(unsigned byte_off, const X &v)
+{
+    constexpr int N = sizeof(X) / sizeof(float);
+    typedef float VT __attribute__((ext_vector_type(N)));
+    using LP = __attribute__((address_space(3))) VT *;
+    union { VT v; X k; } u;
+    u.k = v;
+    *(LP)(size_t)byte_off = u.v;
+}
+
 __device__ __forceinline__ bool wave_uniform(int v, int &vw)
 {
     vw = __builtin_amdgcn_readfirstlane(v);
@@ -124,7 +150,7 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
     }
 #pragma unroll 4
     for (int t = 0; t < trip; ++t) {
-        const P v = *reinterpret_cast<const P *>(smem + base + t * stride);
+        const P v = lds_load<P>(base + t * stride);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float a = __builtin_fabsf(v.x[g]);
@@ -167,14 +193,14 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
 #pragma unroll 4
         for (int t = 0; t < trip; ++t) {
             const unsigned addr = base + t * stride;
-            const P v = *reinterpret_cast<const P *>(smem + addr);
+            const P v = lds_load<P>(addr);
             P o;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t sel = (__builtin_fabsf(v.x[g]) == m1[g]) ? o2[g] : o1[g];
                 o.x[g] = __uint_as_float(sel ^ (__float_as_uint(v.x[g]) & 0x80000000u));
             }
-            *reinterpret_cast<P *>(smem + addr) = o;
+            lds_store<P>(addr, o);
         }
         return;
     }
@@ -187,7 +213,7 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
         const float b = BPC ? b_check : beta_row[pl.bslot[slot]];
         float oa = 0.0f;
         if (FORM == FORM_OMS && oa_row) oa = oa_row[pl.oaslot[slot]];
-        const P v = *reinterpret_cast<const P *>(smem + addr);
+        const P v = lds_load<P>(addr);
         P o;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -210,7 +236,7 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
                 o.x[g] = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
             }
         }
-        *reinterpret_cast<P *>(smem + addr) = o;
+        lds_store<P>(addr, o);
         slot += sstride;
     }
 }
@@ -259,7 +285,7 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
     const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
     P x[DV > 0 ? DV : 1];
 #pragma unroll
-    for (int k = 0; k < DV; ++k) x[k] = *reinterpret_cast<const P *>(smem + off[k]);
+    for (int k = 0; k < DV; ++k) x[k] = lds_load<P>(off[k]);
     P l = L[q];
     if constexpr (MODE == 0 || MODE == 2) {
         P out[DV > 0 ? DV : 1];
@@ -279,7 +305,7 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
             if constexpr (DV >= 8) out[7].x[g] = v2c(l.x[g], sum_ct<DV - 1, 7, 0, float>(xs));
         }
 #pragma unroll
-        for (int k = 0; k < DV; ++k) *reinterpret_cast<P *>(smem + off[k]) = out[k];
+        for (int k = 0; k < DV; ++k) lds_store<P>(off[k], out[k]);
     } else {
         unsigned byte = 0;
         bool store = false;
@@ -312,6 +338,7 @@ __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__r
 
 // Index data (degree, alpha column, the slot offsets) of the NEXT variable of a lane is fetched from
 // global memory (L1/L2 resident, shared by every workgroup) while the current one is processed.
+// (A two-register-set ping-pong that avoids the hand-over copies doubled the code and measured no faster.)
 template <int G, int MODE>
 __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned char *smem,
                                               float *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
@@ -414,6 +441,7 @@ template <int G, int FORM, bool BPC, int NL, int MS>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // lds_load/lds_store rely on that (folds away)
     const int n_alpha_lds = a.alpha_in_lds ? a.T * a.n_alpha : 0;
     float *llr_s = reinterpret_cast<float *>(res_smem + res_off_llr(pl.S, G));
     float *alpha_s = reinterpret_cast<float *>(res_smem + res_off_alpha(pl.S, pl.n, G));
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (k < dv) *reinterpret_cast<P *>(res_smem + off[k]) = l;
+                if (k < dv) lds_store<P>(off[k], l);
         }
     }
     // first-round check degree (iteration-invariant) and per-check beta of iteration 0, in registers
