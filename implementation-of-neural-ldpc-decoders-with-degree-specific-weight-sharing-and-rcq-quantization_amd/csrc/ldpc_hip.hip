@@ -547,7 +547,8 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
     { const char *pad = getenv("LDPC_RES_LDS_PAD"); if (pad && atoi(pad) > 0) lds = std::min<size_t>(lds + atoi(pad), 160 * 1024); }  // occupancy experiments
 #define LDPC_RES_MS(FORM, NL, MS)                                                                        \
     do {                                                                                                 \
-        auto kfn = d->res.bslot_c ? resident_decode<G, FORM, true, NL, MS> : resident_decode<G, FORM, false, NL, MS>; \
+        auto kfn = d->res.bslot_c ? (a.early_stop ? resident_decode<G, FORM, true, NL, MS, 1> : resident_decode<G, FORM, true, NL, MS, 0>)   \
+                                  : (a.early_stop ? resident_decode<G, FORM, false, NL, MS, 1> : resident_decode<G, FORM, false, NL, MS, 0>); \
         HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
     } while (0)

@@ -262,11 +262,13 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
             dc = pl.dc_s[p];
             b_check = BPC ? beta_row[pl.bslot_c[p]] : 0.0f;
         }
-        int dcw;
-        if (wave_uniform(dc, dcw))
-            res_check_body<G, FORM, BPC, true, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
-        else
-            res_check_body<G, FORM, BPC, false, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+        for (bool pending = true; pending;) {            // wave-uniform trip count per distinct degree (see res_var_phase)
+            const int dcw = __builtin_amdgcn_readfirstlane(dc);
+            if (dc == dcw) {
+                res_check_body<G, FORM, BPC, true, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+                pending = false;
+            }
+        }
     }
 }
 
@@ -275,6 +277,8 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
 // MODE 2: the same with alpha == 1 everywhere (1.0f * x == x exactly, the multiply is skipped)
 // MODE 1: posterior -> hard-decision byte bits_s[q]; components in `emask` also overwrite their
 //         (dead) LLR slot with the posterior so the output pass can read it in original order
+// MODE 4 / 6: MODE 0 / 2 plus the hard-decision byte from the same gathered values -- the early-stop
+//         iteration of callers that do not ask for the posterior (one gather pass instead of two)
 template <int G, int DV, int MODE>
 __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restrict__ llr_s,
                                              uint8_t *__restrict__ bits_s, int q, const uint4 &slo, const uint4 &shi,
@@ -287,14 +291,16 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
 #pragma unroll
     for (int k = 0; k < DV; ++k) x[k] = lds_load<P>(off[k]);
     P l = L[q];
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 6) {
         P out[DV > 0 ? DV : 1];
-        auto v2c = [&](float llr, float sum) { return MODE == 2 ? llr + sum : llr + a * sum; };
+        auto v2c = [&](float llr, float sum) { return (MODE & 2) ? llr + sum : llr + a * sum; };
+        unsigned byte = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float xs[DV > 0 ? DV : 1];
 #pragma unroll
             for (int k = 0; k < DV; ++k) xs[k] = x[k].x[g];
+            if constexpr ((MODE & 4) != 0) byte |= ((l.x[g] + sum_ct<DV, -1, 0, float>(xs)) < 0.0f ? 1u : 0u) << g;
             if constexpr (DV >= 1) out[0].x[g] = v2c(l.x[g], sum_ct<DV - 1, 0, 0, float>(xs));
             if constexpr (DV >= 2) out[1].x[g] = v2c(l.x[g], sum_ct<DV - 1, 1, 0, float>(xs));
             if constexpr (DV >= 3) out[2].x[g] = v2c(l.x[g], sum_ct<DV - 1, 2, 0, float>(xs));
@@ -306,6 +312,7 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) lds_store<P>(off[k], out[k]);
+        if constexpr ((MODE & 4) != 0) bits_s[q] = (uint8_t)byte;
     } else {
         unsigned byte = 0;
         bool store = false;
@@ -368,12 +375,16 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
         }
         const int dv = (int)(meta & 0xffu);
         float a = 0.0f;                                                  // LDS copy of the table when small
-        if (MODE == 0) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
-        int dvw;
-        if (wave_uniform(dv, dvw))
-            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);      // scalar branch
-        else
-            res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask);       // class-boundary wave
+        if (MODE == 0 || MODE == 4) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
+        // one scalar branch into the body of the wave's degree; a class-boundary wave (two or three degrees)
+        // goes round once per distinct degree with the other lanes masked off
+        for (bool pending = true; pending;) {
+            const int dvw = __builtin_amdgcn_readfirstlane(dv);
+            if (dv == dvw) {
+                res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);
+                pending = false;
+            }
+        }
         q = qn; meta = metan; slo = slon; shi = shin;
     }
 }
@@ -430,6 +441,33 @@ __device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentA
     }
 }
 
+// outputs of codeword g when no posterior was asked for: hard decisions straight from bits_s (sorted order)
+template <int G>
+__device__ __forceinline__ void res_emit_bits(const ResidentPlan &pl, const ResidentArgs &a, const uint8_t *__restrict__ bits_s,
+                                              long long b, int g, int iters, int success, int tid, int nt)
+{
+    const int n = pl.n;
+    if (a.bits) {
+        for (int j = tid; j < n; j += nt) a.bits[(size_t)b * n + j] = (bits_s[pl.inv_perm_v[j]] >> g) & 1;
+    }
+    if (a.packed) {
+        const int nbytes = (n + 7) / 8;
+        for (int k = tid; k < nbytes; k += nt) {
+            unsigned v = 0;
+#pragma unroll
+            for (int qb = 0; qb < 8; ++qb) {
+                const int j = k * 8 + qb;
+                if (j < n) v |= (unsigned)((bits_s[pl.inv_perm_v[j]] >> g) & 1) << qb;
+            }
+            a.packed[(size_t)b * nbytes + k] = (uint8_t)v;
+        }
+    }
+    if (tid == 0) {
+        if (a.iterations) a.iterations[b] = iters;
+        if (a.success) a.success[b] = (uint8_t)success;
+    }
+}
+
 // LDS carve (bytes): msg at 0, then llr_s, alpha_s, bits_s, the syndrome word
 __host__ __device__ inline size_t res_off_llr(int S, int G) { return (size_t)S * G * 4; }
 __host__ __device__ inline size_t res_off_alpha(int S, int n, int G) { return res_off_llr(S, G) + (size_t)n * G * 4; }
@@ -437,7 +475,9 @@ __host__ __device__ inline size_t res_off_bits(int S, int n, int G, int n_alpha_
 __host__ __device__ inline size_t res_off_flag(int S, int n, int G, int n_alpha_lds) { return (res_off_bits(S, n, G, n_alpha_lds) + n + 3) / 4 * 4; }
 __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
 
-template <int G, int FORM, bool BPC, int NL, int MS>
+// ES: 0 = fixed-iteration kernel, 1 = early-stop kernel (kept apart so that the fixed-T kernel does not carry
+// the posterior/syndrome/emit code of the stop rule: the extra code cost the hot loop ~4 % when merged)
+template <int G, int FORM, bool BPC, int NL, int MS, int ES>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
@@ -504,7 +544,31 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
         __syncthreads();
-        if (a.early_stop) {
+        if (ES && !a.posterior) {
+            // reference stop rule without a second gather pass: the variable phase also yields this iteration's
+            // hard decisions (the posterior shares the gathered C2V values); outputs are bits only
+            const bool last = it == a.T - 1;
+            if (last) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
+            else if (a.unit_alpha) res_var_phase<G, 6>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
+            else res_var_phase<G, 4>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
+            __syncthreads();
+            res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
+            __syncthreads();
+            const unsigned unsat = *sh_unsat;
+            __syncthreads();
+            if (tid == 0) *sh_unsat = 0;
+            const unsigned newly = ~unsat & ~done & kAll;
+            if (newly) {                                 // block-uniform
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if ((newly >> g) & 1u) res_emit_bits<G>(pl, a, bits_s, b0 + g, g, it + 1, 1, tid, nt);
+                done |= newly;
+                if (done == kAll) return;
+                __syncthreads();                         // bits_s is rewritten by the next iteration
+            }
+            continue;
+        }
+        if (ES) {
             res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
             __syncthreads();
             res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
@@ -534,10 +598,16 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // codewords still open after T iterations: outputs of the last iteration
     const unsigned open = ~done & kAll;
     if (!open) return;
+    if (ES && !a.posterior && a.T > 0) {                 // bits_s hold iteration T's decisions already
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if ((open >> g) & 1u) res_emit_bits<G>(pl, a, bits_s, b0 + g, g, a.T, 0, tid, nt);
+        return;
+    }
     if (!LDPC_PROBE(a, 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
     __syncthreads();
     unsigned unsat = kAll;
-    if (!a.early_stop && !LDPC_PROBE(a, 8)) {          // fixed-T mode: success = final syndrome is zero
+    if (!ES && !LDPC_PROBE(a, 8)) {                    // fixed-T mode: success = final syndrome is zero
         res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
