@@ -41,7 +41,7 @@ def build_native(force: bool = False, verbose: bool = False, defines=(), out: Op
     """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir.
     `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
     srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"),
-            os.path.join(CSRC, "ldpc_resident.hip"), HEADER]
+            os.path.join(CSRC, "ldpc_resident.hip"), os.path.join(CSRC, "ldpc_train.hip"), HEADER]
     target = out or os.path.join(_HERE, LIB_NAME)
     if not force and os.path.exists(target) and all(
             os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
@@ -71,7 +71,8 @@ class DecoderDesc(C.Structure):
 EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
            "ldpc_decoder_set_mode", "ldpc_decoder_info",
            "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
-           "ldpc_decode", "ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_last_error", "ldpc_abi_version")
+           "ldpc_decode", "ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_last_error", "ldpc_abi_version",
+           "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
 
 _lib = None
 _lock = threading.Lock()
@@ -118,6 +119,14 @@ def load():
         lib.ldpc_debug_sweep.argtypes = [vp, i64, i32, i32, vp, C.c_size_t, vp]
         lib.ldpc_debug_workspace_layout.restype = C.c_int
         lib.ldpc_debug_workspace_layout.argtypes = [vp, i64, vp]
+        lib.ldpc_train_saved_bytes.restype = C.c_size_t
+        lib.ldpc_train_saved_bytes.argtypes = [vp, i64]
+        lib.ldpc_train_workspace_bytes.restype = C.c_size_t
+        lib.ldpc_train_workspace_bytes.argtypes = [vp, i64]
+        lib.ldpc_decode_saving.restype = C.c_int
+        lib.ldpc_decode_saving.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]
+        lib.ldpc_backward.restype = C.c_int
+        lib.ldpc_backward.argtypes = [vp, vp, C.c_size_t, vp, i64, vp, vp, vp, vp, vp, C.c_size_t, vp]
         lib.ldpc_last_error.restype = C.c_char_p
         lib.ldpc_last_error.argtypes = []
         lib.ldpc_abi_version.restype = C.c_int

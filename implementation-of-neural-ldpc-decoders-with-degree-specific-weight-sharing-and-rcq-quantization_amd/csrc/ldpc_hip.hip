@@ -5,6 +5,7 @@
 // (graph-capturable); all work goes to the caller's stream.
 #include "ldpc_kernels.hip"
 #include "ldpc_resident.hip"
+#include "ldpc_train.hip"
 
 #include <algorithm>
 #include <cmath>
@@ -220,10 +221,27 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
     return LDPC_OK;
 }
 
+// Saved forward state of the training path: c2v rows of iterations 0..T-1, then the v2c input rows of
+// iterations 1..T-1 (iteration 0 reads the LLRs), each slice [tile][E][W] fp32.
+struct SavedLayout {
+    size_t slice = 0;
+    int T = 0;
+    size_t c2v_off(int it) const { return (size_t)it * slice; }
+    size_t v2c_off(int it) const { return ((size_t)T + (size_t)(it - 1)) * slice; }      // it >= 1
+    size_t total() const { return T > 0 ? (size_t)(2 * T - 1) * slice : 0; }
+};
+SavedLayout saved_layout(const ldpc_decoder *d, int tiles, int W)
+{
+    SavedLayout sl;
+    sl.T = d->T;
+    sl.slice = align_up((size_t)tiles * W * std::max(d->g->E, 1) * sizeof(float));
+    return sl;
+}
+
 template <typename T, int VEC>
 int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool early_stop, int32_t *bits,
                 void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed,
-                const Workspace &w, hipStream_t s)
+                const Workspace &w, hipStream_t s, char *saved = nullptr)
 {
     constexpr int W = 64 * VEC;
     constexpr int JT = 128 / sizeof(T);
@@ -272,8 +290,19 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     for (int it = 0; it < T_it; ++it) {
         int rc = launch_cn<T, VEC>(d, w, it, early_stop, s);
         if (rc) return rc;
+        // training forward: keep this iteration's c2v rows, and the v2c rows the next one will read, in `saved`
+        // (layout: SavedLayout).  Copies of the working buffers, because a stopped codeword's rows must stay
+        // latched in the working buffers -- the final variable sweep forms its posterior from them.
+        const size_t msg_bytes = (size_t)w.tiles * W * g.E * sizeof(T);
+        SavedLayout sl;
+        if (saved) {
+            sl = saved_layout(d, w.tiles, W);
+            HIP_TRY(hipMemcpyAsync(saved + sl.c2v_off(it), w.c2v, msg_bytes, hipMemcpyDeviceToDevice, s));
+        }
         rc = launch_vn<T, VEC>(d, w, it, it == T_it - 1, early_stop, s);
         if (rc) return rc;
+        if (saved && it + 1 < T_it)
+            HIP_TRY(hipMemcpyAsync(saved + sl.v2c_off(it + 1), w.v2c, msg_bytes, hipMemcpyDeviceToDevice, s));
         if (early_stop) {
             hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
                                w.iters, it + 1, 1);
@@ -305,17 +334,17 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
 template <typename T>
 int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool early_stop, int32_t *bits,
                     void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed,
-                    const Workspace &w, hipStream_t s)
+                    const Workspace &w, hipStream_t s, char *saved = nullptr)
 {
     switch (w.vec) {
-    case 1: return decode_impl<T, 1>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+    case 1: return decode_impl<T, 1>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s, saved);
     case 2:
         if constexpr (sizeof(T) == 8)
-            return decode_impl<T, 2>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+            return decode_impl<T, 2>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s, saved);
         break;
     case 4:
         if constexpr (sizeof(T) == 4)
-            return decode_impl<T, 4>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s);
+            return decode_impl<T, 4>(d, llr, batch, early_stop, bits, posterior, iterations, success, packed, w, s, saved);
         break;
     }
     return fail(LDPC_ERR_ARG, "internal: bad tile width");
@@ -837,6 +866,160 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
     if (d->dtype == LDPC_F64)
         return decode_dispatch<double>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
     return decode_dispatch<float>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
+}
+
+}  // extern "C"
+
+// ---- gradient (training) path: ldpc_train.hip ----------------------------------------------------------------
+namespace {
+int train_supported(const ldpc_decoder *d)
+{
+    if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
+    if (d->dtype != LDPC_F32 || d->form != LDPC_C2V_NMS || d->schedule != LDPC_SCHED_FLOODING)
+        return fail(LDPC_ERR_UNSUPPORTED, "gradients exist for fp32 normalised min-sum flooding decoders only "
+                                          "(the RCQ quantiser and the offset form's relu are not trained by the reference)");
+    return LDPC_OK;
+}
+
+struct BackwardWs {
+    int vec = 0, tiles = 0;
+    float *llrT = nullptr, *gpostT = nullptr, *gv2c = nullptr, *gc2v = nullptr, *gbeta = nullptr, *galpha = nullptr;
+    size_t part_bytes = 0, total = 0;
+};
+BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
+{
+    BackwardWs w;
+    w.vec = pick_vec(d, batch);
+    const int W = 64 * w.vec;
+    w.tiles = (int)std::max<int64_t>((batch + W - 1) / W, 1);
+    const size_t n = d->g->n, E = std::max(d->g->E, 1), tw = (size_t)w.tiles * W, T = std::max(d->T, 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_llr = take(tw * n * 4), o_gp = take(tw * n * 4), o_gv = take(tw * E * 4), o_gc = take(tw * E * 4);
+    const size_t o_gb = take(T * w.tiles * E * 4), o_ga = take(T * w.tiles * n * 4);
+    w.part_bytes = off - o_gb;
+    w.total = off;
+    if (base) {
+        char *b = (char *)base;
+        w.llrT = (float *)(b + o_llr); w.gpostT = (float *)(b + o_gp); w.gv2c = (float *)(b + o_gv);
+        w.gc2v = (float *)(b + o_gc); w.gbeta = (float *)(b + o_gb); w.galpha = (float *)(b + o_ga);
+    }
+    return w;
+}
+
+template <int VEC>
+int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, int64_t batch, const int32_t *iterations,
+                  const float *grad_posterior, float *grad_beta, float *grad_alpha, const BackwardWs &w, hipStream_t s)
+{
+    constexpr int W = 64 * VEC;
+    constexpr int JT = 32;
+    const GraphDev g = d->g->dev();
+    const int T = d->T, vc = (g.n + JT - 1) / JT;
+    const SavedLayout sl = saved_layout(d, w.tiles, W);
+    const dim3 tgrid((unsigned)((size_t)w.tiles * vc)), blk(kBlock);
+    hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, llr, w.llrT, (long long)batch, g.n, vc);
+    hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, grad_posterior, w.gpostT, (long long)batch, g.n, vc);
+    HIP_TRY(hipMemsetAsync(w.gbeta, 0, w.part_bytes, s));
+    const int cb = (g.m + kWavesPerBlock - 1) / kWavesPerBlock, vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 cgrid((unsigned)((size_t)w.tiles * cb)), vgrid((unsigned)((size_t)w.tiles * vb));
+    const size_t epart = (size_t)w.tiles * g.E, vpart = (size_t)w.tiles * g.n;
+    for (int t = T - 1; t >= 0; --t) {
+        const float *beta_row = (const float *)d->beta + (size_t)t * d->n_beta;
+        // d loss/d c2v_t is in w.gc2v (written by the variable pass of step t+1; unread at t == T-1)
+        if (t == 0) {
+            hipLaunchKernelGGL((cn_backward<VEC, true>), cgrid, blk, 0, s, g, (const float *)w.llrT, (const float *)w.gc2v,
+                               (const float *)w.gpostT, iterations, (long long)batch, t, beta_row, (const int *)d->beta_slot,
+                               (float *)nullptr, w.gbeta + (size_t)t * epart, cb);
+        } else {
+            hipLaunchKernelGGL((cn_backward<VEC, false>), cgrid, blk, 0, s, g, (const float *)(saved + sl.v2c_off(t)),
+                               (const float *)w.gc2v, (const float *)w.gpostT, iterations, (long long)batch, t, beta_row,
+                               (const int *)d->beta_slot, w.gv2c, w.gbeta + (size_t)t * epart, cb);
+            const float *alpha_row = (const float *)d->alpha + (size_t)(t - 1) * d->n_alpha;
+            hipLaunchKernelGGL((vn_backward<VEC>), vgrid, blk, 0, s, g, (const float *)(saved + sl.c2v_off(t - 1)),
+                               (const float *)w.gv2c, iterations, (long long)batch, t, alpha_row, (const int *)d->alpha_slot,
+                               w.gc2v, w.galpha + (size_t)(t - 1) * vpart, vb);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (grad_beta) {
+        HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)T * d->n_beta * 4, s));
+        const long long cnt = (long long)T * g.E;
+        if (cnt > 0)
+            hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float *)w.gbeta,
+                               T, w.tiles, g.E, (const int *)d->beta_slot, d->n_beta, grad_beta);
+    }
+    if (grad_alpha) {
+        HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)T * d->n_alpha * 4, s));
+        const long long cnt = (long long)T * g.n;
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float *)w.galpha,
+                           T, w.tiles, g.n, (const int *)d->alpha_slot, d->n_alpha, grad_alpha);
+    }
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t ldpc_train_saved_bytes(const ldpc_decoder *d, int64_t batch)
+{
+    if (!d || batch <= 0) return 0;
+    const int vec = pick_vec(d, batch), W = 64 * vec;
+    const size_t total = saved_layout(d, (int)((batch + W - 1) / W), W).total();
+    return total ? total : kAlign;
+}
+
+size_t ldpc_train_workspace_bytes(const ldpc_decoder *d, int64_t batch)
+{
+    if (!d || batch < 0) return 0;
+    return std::max(carve(d, batch, nullptr).total, carve_backward(d, batch, nullptr).total);
+}
+
+int ldpc_decode_saving(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop, int32_t *bits,
+                       void *posterior, int32_t *iterations, uint8_t *success, void *saved, size_t saved_bytes,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = train_supported(d)) return rc;
+    if (batch < 0) return fail(LDPC_ERR_ARG, "batch < 0");
+    if (batch == 0 || d->g->n == 0) return LDPC_OK;
+    if (!llr || !workspace || !saved) return fail(LDPC_ERR_ARG, "NULL llr/workspace/saved");
+    if (((uintptr_t)workspace % kAlign) != 0 || ((uintptr_t)saved % kAlign) != 0)
+        return fail(LDPC_ERR_ARG, "workspace and saved state must be %zu-byte aligned", kAlign);
+    const Workspace w = carve(d, batch, workspace);
+    if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
+    if (ldpc_train_saved_bytes(d, batch) > saved_bytes) return fail(LDPC_ERR_WORKSPACE, "saved-state buffer too small");
+    if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
+    DeviceGuard guard(d->g->device);
+    return decode_dispatch<float>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, nullptr, w,
+                                  (hipStream_t)stream, (char *)saved);
+}
+
+int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, const void *llr, int64_t batch,
+                  const int32_t *iterations, const void *grad_posterior, void *grad_beta, void *grad_alpha,
+                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = train_supported(d)) return rc;
+    if (batch < 0) return fail(LDPC_ERR_ARG, "batch < 0");
+    if (!grad_beta && !grad_alpha) return LDPC_OK;
+    DeviceGuard guard(d->g->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (batch == 0 || d->g->n == 0 || d->T == 0 || d->g->E == 0) {       // no iteration ran: the posterior is the LLR
+        if (grad_beta) HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)std::max(d->T, 1) * d->n_beta * 4, s));
+        if (grad_alpha) HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)std::max(d->T, 1) * d->n_alpha * 4, s));
+        return LDPC_OK;
+    }
+    if (!saved || !llr || !iterations || !grad_posterior || !workspace) return fail(LDPC_ERR_ARG, "NULL argument");
+    if (((uintptr_t)workspace % kAlign) != 0 || ((uintptr_t)saved % kAlign) != 0)
+        return fail(LDPC_ERR_ARG, "workspace and saved state must be %zu-byte aligned", kAlign);
+    if (ldpc_train_saved_bytes(d, batch) > saved_bytes) return fail(LDPC_ERR_WORKSPACE, "saved-state buffer too small");
+    const BackwardWs w = carve_backward(d, batch, workspace);
+    if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
+    if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
+    if (w.vec == 1)
+        return backward_impl<1>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
+                                (float *)grad_beta, (float *)grad_alpha, w, s);
+    return backward_impl<4>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
+                            (float *)grad_beta, (float *)grad_alpha, w, s);
 }
 
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])

@@ -129,6 +129,7 @@ class DecodeEngine:
             desc.oms_alpha, desc.oms_alpha_slot = nat.ptr(oms_alpha), nat.ptr(oms_alpha_slot)
             keep += [oms_alpha, oms_alpha_slot]
         self._table_shapes = (beta.shape, alpha.shape, None if oms_alpha is None else oms_alpha.shape)
+        self._tables = [beta.copy(), alpha.copy()]          # what the device holds (gradient path restores them)
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(lib.ldpc_decoder_create(C.byref(self.handle), self._ng.handle, C.byref(desc)),
@@ -176,6 +177,14 @@ class DecodeEngine:
                                                          nat.ptr(oms_alpha), C.c_void_p(stream.cuda_stream)),
                       "ldpc_decoder_set_weights")
             stream.synchronize()     # pageable host arrays: make the upload complete before they die
+        if beta is not None:
+            self._tables[0] = beta.copy()
+        if alpha is not None:
+            self._tables[1] = alpha.copy()
+
+    def current_tables(self):
+        """(beta [T, Sb], alpha [T, Sa]) numpy copies of the tables the device holds"""
+        return self._tables[0], self._tables[1]
 
     # ------------------------------------------------------------------ decode
     def workspace_bytes(self, batch: int) -> int:
@@ -214,6 +223,64 @@ class DecodeEngine:
                                                 p(iters), p(succ), p(packed), p(ws), ws.numel(),
                                                 C.c_void_p(stream)), "ldpc_decode")
         return DecodeResult(bits, post, iters, succ.bool(), packed)
+
+    # ------------------------------------------------------------------ gradients (training path)
+    def _check_llr(self, llr: torch.Tensor) -> torch.Tensor:
+        if llr.device != self.device:
+            raise ValueError(f"llr is on {llr.device}, engine on {self.device}")
+        if llr.dtype != self.dtype:
+            raise TypeError(f"llr dtype {llr.dtype} != engine dtype {self.dtype}")
+        if llr.dim() != 2 or llr.shape[1] != self.graph.n:
+            raise ValueError(f"llr must have shape [B, {self.graph.n}], got {tuple(llr.shape)}")
+        return llr.contiguous()
+
+    def train_saved_bytes(self, batch: int) -> int:
+        return int(self._lib.ldpc_train_saved_bytes(self.handle, max(int(batch), 1)))
+
+    def decode_saving(self, llr: torch.Tensor, *, early_stop: bool = True):
+        """decode() that also keeps every iteration's messages for backward(); returns (DecodeResult, saved).
+        fp32 normalised min-sum decoders only (NotImplementedError otherwise)."""
+        llr = self._check_llr(llr)
+        B, n = llr.shape
+        dev = self.device
+        bits = torch.empty((B, n), dtype=torch.int32, device=dev)
+        post = torch.empty((B, n), dtype=self.dtype, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        succ = torch.empty((B,), dtype=torch.uint8, device=dev)
+        saved = torch.empty(int(self._lib.ldpc_train_saved_bytes(self.handle, max(B, 1))), dtype=torch.uint8, device=dev)
+        if B > 0:
+            ws = torch.empty(int(self._lib.ldpc_train_workspace_bytes(self.handle, B)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                p = lambda t: C.c_void_p(t.data_ptr())
+                nat.check(self._lib.ldpc_decode_saving(self.handle, p(llr), B, int(bool(early_stop)), p(bits), p(post),
+                                                       p(iters), p(succ), p(saved), saved.numel(), p(ws), ws.numel(),
+                                                       C.c_void_p(stream)), "ldpc_decode_saving")
+        return DecodeResult(bits, post, iters, succ.bool(), None), saved
+
+    def backward(self, saved: torch.Tensor, llr: torch.Tensor, iterations: torch.Tensor, grad_posterior: torch.Tensor):
+        """(d loss/d beta [T, beta slots], d loss/d alpha [T, alpha slots]) for a loss with
+        d loss/d posterior = grad_posterior [B, n]; `saved`, `iterations` from decode_saving of the same llr
+        with the same weight tables."""
+        llr = self._check_llr(llr)
+        B, n = llr.shape
+        dev = self.device
+        gp = grad_posterior.to(device=dev, dtype=torch.float32).contiguous()
+        if gp.shape != llr.shape:
+            raise ValueError(f"grad_posterior must have shape {tuple(llr.shape)}, got {tuple(gp.shape)}")
+        iterations = iterations.to(device=dev, dtype=torch.int32).contiguous()
+        if iterations.shape != (B,):
+            raise ValueError("iterations must have one entry per codeword")
+        gb = torch.zeros(self._table_shapes[0], dtype=torch.float32, device=dev)
+        ga = torch.zeros(self._table_shapes[1], dtype=torch.float32, device=dev)
+        if B > 0:
+            ws = torch.empty(int(self._lib.ldpc_train_workspace_bytes(self.handle, B)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                p = lambda t: C.c_void_p(t.data_ptr())
+                nat.check(self._lib.ldpc_backward(self.handle, p(saved), saved.numel(), p(llr), B, p(iterations), p(gp),
+                                                  p(gb), p(ga), p(ws), ws.numel(), C.c_void_p(stream)), "ldpc_backward")
+        return gb, ga
 
     def debug_sweep(self, batch: int, which: int, it: int):
         """Launch one CN (which=0) or VN (which=1) sweep on the state a previous

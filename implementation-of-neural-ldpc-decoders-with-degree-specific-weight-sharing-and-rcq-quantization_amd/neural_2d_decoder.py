@@ -141,10 +141,34 @@ class Neural2DMinSumDecoder(_DegreeSharedDecoder):
         Returns:
             decoded_bits (int32), posterior (float32), iterations (int, or int32[B])
         """
+        import autograd_bridge as ab
+        if ab.wants_grad(self):
+            out = self._decode_with_grad(llr, early_stop, device)
+            if out is not None:
+                return out
         res, single, out_dev = self._decode(llr, early_stop, device)
         if single:
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())
         return res.bits.to(out_dev), res.posterior.to(out_dev), res.iterations.to(out_dev)
+
+    def _decode_with_grad(self, llr, early_stop, device):
+        """the reference's posterior carries a grad_fn back to beta/alpha (neural_2d_decoder.py:189-209);
+        here the HIP backward sweeps provide it (autograd_bridge.py)"""
+        import autograd_bridge as ab
+        if not isinstance(llr, torch.Tensor):
+            raise TypeError("llr must be a torch.Tensor")
+        _, x, single = _as_batch(llr, self.code.n)
+        eng = self._get_engine(x.device if x.is_cuda else device)       # uploads the current parameter values
+        if not ab.saved_state_fits(eng, x.shape[0]):
+            return None
+        bt, at = self._sharing_layout().tables_torch(self.beta_weights, self.alpha_weights, int(self.max_iterations),
+                                                     self._beta_default, self._alpha_default)
+        xd = x.detach().to(device=eng.device, dtype=torch.float32)
+        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop))
+        out_dev = llr.device
+        if single:
+            return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
+        return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
 
 
 class Neural2DOffsetMinSumDecoder(_DegreeSharedDecoder):

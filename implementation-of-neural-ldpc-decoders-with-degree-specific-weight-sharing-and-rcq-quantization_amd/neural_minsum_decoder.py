@@ -98,8 +98,22 @@ class _EdgeWeightDecoder(nn.Module):
             raise TypeError("llr must be a torch.Tensor")
         _, x, single = _as_batch(llr, self.code.n)
         eng = self._get_engine(x.device if x.is_cuda else device)
-        res = eng.decode(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
         out_dev = llr.device
+        import autograd_bridge as ab
+        if self._c2v_form == "nms" and ab.wants_grad(self) and ab.saved_state_fits(eng, x.shape[0]):
+            # posterior with a grad_fn back to the edge weights, as in the reference (neural_minsum_decoder.py:100-139)
+            g, T = self.code.tanner_graph(), int(self.max_iterations)
+            rows, cols = g.check_of_edge.tolist(), g.var_idx.tolist()
+            params = [self.beta_weights[f"iter_{t}_c{i}_v{j}"] for t in range(T) for i, j in zip(rows, cols)]
+            where = [(t, e) for t in range(T) for e in range(g.E)]
+            bt = ab.table_from_params(params, where, (max(T, 1), max(g.E, 1)), 0.0)
+            at = torch.ones((max(T, 1), 1), dtype=torch.float32)
+            post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, x.detach().to(device=eng.device, dtype=torch.float32),
+                                                        bool(early_stop))
+            if single:
+                return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
+            return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
+        res = eng.decode(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
         if single:
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())
         return res.bits.to(out_dev), res.posterior.to(out_dev), res.iterations.to(out_dev)

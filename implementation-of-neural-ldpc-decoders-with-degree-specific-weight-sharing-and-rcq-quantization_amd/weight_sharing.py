@@ -123,6 +123,22 @@ class SharingLayout:
             out[list(tt), list(ss)] = vals
         return out
 
+    @staticmethod
+    def _table_torch(params, suffixes, T: int, default: float) -> torch.Tensor:
+        """the same table as a differentiable function of the parameters (gradient path)"""
+        from autograd_bridge import table_from_params
+        picks, where = [], []
+        for t in range(T):
+            for s, suf in enumerate(suffixes):
+                if suf is not None and f"iter_{t}_{suf}" in params:
+                    picks.append(params[f"iter_{t}_{suf}"])
+                    where.append((t, s))
+        return table_from_params(picks, where, (max(T, 1), len(suffixes)), default)
+
+    def tables_torch(self, beta_params, alpha_params, T: int, beta_default: float, alpha_default: float):
+        return (self._table_torch(beta_params, self.beta_suffix, T, beta_default),
+                self._table_torch(alpha_params, self.alpha_suffix, T, alpha_default))
+
     def tables(self, beta_params, alpha_params, T: int, beta_default: float, alpha_default: float):
         """-> (beta[T, Sb], alpha[T, Sa]) float32, one device->host copy per dict."""
         return (self._table(beta_params, self.beta_suffix, T, beta_default),

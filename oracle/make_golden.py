@@ -20,6 +20,8 @@ Sets:
   small_*        the same on the 48x96 code (variable degrees 1,2,3,8)
   ira_*          (1998,1512) code: Basic x16, Neural2D x2, RCQ x4, W-RCQ x2
   dvbs2_wrcq     (16200,7200) W-RCQ T=20, 1 codeword              (--slow, ~15 min)
+  grad_toy/small d loss/d beta, d loss/d alpha of the reference under torch autograd (the loss of
+                 training_framework.py:101), Neural2D types 1-4 and the per-edge NeuralMinSumDecoder
 """
 import argparse
 import os
@@ -568,6 +570,105 @@ def gen_dvbs2_wrcq():
     return out
 
 
+def _ref_grads(dec, llrs, targets=None):
+    """The REAL reference under autograd: per codeword loss = binary_cross_entropy_with_logits(-posterior, target)
+    (training_framework.py:101), backward, gradients summed over the codewords.  Parameters autograd leaves
+    without a gradient (None) count as 0; a posterior without grad_fn (no parameter on its path) adds nothing."""
+    import torch.nn.functional as F
+    gb = {k: 0.0 for k in dec.beta_weights.keys()}
+    ga = {k: 0.0 for k in getattr(dec, "alpha_weights", {}).keys()}
+    post, its, losses = [], [], []
+    for b, x in enumerate(llrs):
+        dec.zero_grad()
+        _, p, i = dec(torch.from_numpy(x.copy()))
+        tgt = torch.zeros_like(p) if targets is None else torch.from_numpy(targets[b].astype(np.float32))
+        loss = F.binary_cross_entropy_with_logits(-p, tgt)
+        if p.requires_grad:
+            loss.backward()
+        for k, w in dec.beta_weights.items():
+            if w.grad is not None:
+                gb[k] += float(w.grad.item())
+        for k, w in getattr(dec, "alpha_weights", {}).items():
+            if w.grad is not None:
+                ga[k] += float(w.grad.item())
+        post.append(p.detach().numpy().reshape(-1).copy()); its.append(int(i)); losses.append(float(loss.item()))
+    return gb, ga, np.stack(post), np.asarray(its, np.int32), np.asarray(losses, np.float64)
+
+
+def _check_grad_oracle(name, g, llrs, bt, bs, at, as_, T, gb_ref, ga_ref, post, its):
+    import grad_oracle
+    ogb, oga, opost, oit = grad_oracle.table_grads(g, llrs, bt, bs, at, as_, T)
+    check_equal(name + " iters", oit.astype(np.int32), its)
+    if not np.allclose(opost, post, rtol=1e-5, atol=1e-5):
+        raise SystemExit(f"GRAD ORACLE MISMATCH ({name}): posterior")
+    # a table column that is a constant of the sharing type (no reference parameter behind it) has no reference gradient
+    for tag, a, b in (("beta", ogb, gb_ref), ("alpha", oga, ga_ref)):
+        if b is not None and not np.allclose(a, b, rtol=2e-4, atol=2e-6):
+            raise SystemExit(f"GRAD ORACLE MISMATCH ({name}): d loss/d {tag}: max |diff| {np.abs(a - b).max()}")
+
+
+def run_grad_neural2d(code, H, llrs, wtype, T, rng):
+    g = oracle.OracleGraph(H)
+    dec = ref_n2d.Neural2DMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=T)
+    beta, alpha = set_weights(dec, rng)
+    gb, ga, post, its, losses = _ref_grads(dec, llrs)
+    bt, bs, at, as_ = oracle.weight_tables(g, wtype, T, beta, alpha)
+    # reference per-key gradients -> the [T][slots] tables of the engines (independent flattening: oracle.weight_tables)
+    gbt, _, gat, _ = oracle.weight_tables(g, wtype, T, gb, ga, beta_default=0.0, alpha_default=0.0)
+    _check_grad_oracle(f"n2d type {wtype}", g, llrs, bt, bs, at, as_, T, gbt if gb else None, gat if ga else None, post, its)
+    bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+    return dict(llr=llrs, posterior=post, iters=its, loss=losses, wtype=np.int32(wtype), T=np.int32(T),
+                beta_keys=bk, beta_vals=bv, alpha_keys=ak, alpha_vals=av,
+                grad_beta_keys=pack_weights(gb)[0], grad_beta_vals=np.asarray([gb[k] for k in sorted(gb)], np.float64),
+                grad_alpha_keys=pack_weights(ga)[0], grad_alpha_vals=np.asarray([ga[k] for k in sorted(ga)], np.float64),
+                grad_beta_table=gbt.astype(np.float64), grad_alpha_table=gat.astype(np.float64))
+
+
+def run_grad_edge(code, H, llrs, T, seed):
+    """NeuralMinSumDecoder (one beta per edge and iteration, neural_minsum_decoder.py:58-150) under autograd"""
+    g = oracle.OracleGraph(H)
+    torch.manual_seed(seed)
+    dec = ref_nms.NeuralMinSumDecoder(code, max_iterations=T)
+    with torch.no_grad():                                   # randn * 0.1 init -> useful decoding range
+        for w in dec.beta_weights.values():
+            w.mul_(1.5).add_(0.75)
+    beta = {k: float(v.detach().item()) for k, v in dec.beta_weights.items()}
+    gb, _, post, its, losses = _ref_grads(dec, llrs)
+    bt = oracle.edge_weight_table(g, T, beta)
+    gbt = oracle.edge_weight_table(g, T, gb).astype(np.float64)
+    ones, zslot = np.ones((max(T, 1), 1), np.float32), np.zeros(g.n, np.int32)
+    _check_grad_oracle("edge", g, llrs, bt, np.arange(g.E, dtype=np.int32), ones, zslot, T, gbt, None, post, its)
+    bk, bv = pack_weights(beta)
+    return dict(llr=llrs, posterior=post, iters=its, loss=losses, T=np.int32(T), seed=np.int32(seed),
+                beta_keys=bk, beta_vals=bv, grad_beta_table=gbt)
+
+
+def gen_grad(which):
+    rng = np.random.default_rng(8642)
+    if which == "toy":
+        code = ref_ldpc.create_test_ldpc_code()
+        H = code.H
+        llrs = np.concatenate([toy_inputs_fp64(32)[8:24].astype(np.float32),          # both sign conventions
+                               rng.normal(0.8, 1.6, (8, 7)).astype(np.float32)])
+        out = {"H": H.astype(np.uint8)}
+        for wtype in (1, 2, 3, 4):
+            for T in (3, 6):
+                for k, v in run_grad_neural2d(code, H, llrs, wtype, T, rng).items():
+                    out[f"t{wtype}_T{T}_{k}"] = v
+        for k, v in run_grad_edge(code, H, llrs, 4, seed=77).items():
+            out[f"edge_{k}"] = v
+    else:
+        H = load_edge_list("small_96_48")
+        code = CachedCode(n=96, k=48, H=H, max_iterations=10)
+        llrs = np.concatenate([awgn_llr_decoder_convention(rng, 4, 96, 2.0, np.float32),
+                               awgn_llr_decoder_convention(rng, 3, 96, 4.5, np.float32)])
+        out = {"graph": np.asarray("small_96_48")}
+        for wtype, T in ((2, 4), (1, 3)):
+            for k, v in run_grad_neural2d(code, H, llrs, wtype, T, rng).items():
+                out[f"t{wtype}_T{T}_{k}"] = v
+    return out
+
+
 SETS = {
     "quantizer": gen_quantizer,
     "sums": gen_sums,
@@ -584,6 +685,8 @@ SETS = {
     "toy_offset_edge": lambda: gen_offset_and_edge("toy"),
     "small_offset_edge": lambda: gen_offset_and_edge("small"),
     "layered_rcq": gen_layered,
+    "grad_toy": lambda: gen_grad("toy"),
+    "grad_small": lambda: gen_grad("small"),
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 
