@@ -27,6 +27,7 @@ logger = logging.getLogger(__name__)
 # return a posterior without grad_fn (and say so once) instead of exhausting HBM
 MAX_SAVED_BYTES = int(os.environ.get("LDPC_TRAIN_MAX_SAVED_BYTES", str(64 << 30)))
 _warned = False
+RECYCLE_SAVED = True        # release the saved messages to the engine's spare slot after backward (see backward())
 
 
 def wants_grad(module: torch.nn.Module) -> bool:
@@ -63,6 +64,9 @@ class MinSumDecodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_post, _g_bits, _g_iters):
         eng = ctx.engine
+        if ctx.saved is None:
+            raise RuntimeError("the saved messages of this decode were released by its first backward; for "
+                               "backward(retain_graph=True) set autograd_bridge.RECYCLE_SAVED = False")
         held = eng.current_tables()
         same = np.array_equal(held[0], ctx.tables[0]) and np.array_equal(held[1], ctx.tables[1])
         if not same:                       # the weights moved on since this forward: put its tables back for the sweep
@@ -72,6 +76,9 @@ class MinSumDecodeFn(torch.autograd.Function):
         finally:
             if not same:
                 eng.set_weights(held[0], held[1])
+        if RECYCLE_SAVED:                  # GBs of messages: hand the buffer to the next forward instead of the allocator
+            eng.recycle_saved(ctx.saved)
+            ctx.saved = None
         bdev, bdt, adev, adt = ctx.meta
         return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None
 

@@ -943,16 +943,13 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     HIP_TRY(hipGetLastError());
     if (grad_beta) {
         HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)T * d->n_beta * 4, s));
-        const long long cnt = (long long)T * g.E;
-        if (cnt > 0)
-            hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float *)w.gbeta,
-                               T, w.tiles, g.E, (const int *)d->beta_slot, d->n_beta, grad_beta);
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                           (const float *)w.gbeta, w.tiles, g.E, (const int *)d->beta_slot, d->n_beta, grad_beta);
     }
     if (grad_alpha) {
         HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)T * d->n_alpha * 4, s));
-        const long long cnt = (long long)T * g.n;
-        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float *)w.galpha,
-                           T, w.tiles, g.n, (const int *)d->alpha_slot, d->n_alpha, grad_alpha);
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.n + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                           (const float *)w.galpha, w.tiles, g.n, (const int *)d->alpha_slot, d->n_alpha, grad_alpha);
     }
     HIP_TRY(hipGetLastError());
     return LDPC_OK;

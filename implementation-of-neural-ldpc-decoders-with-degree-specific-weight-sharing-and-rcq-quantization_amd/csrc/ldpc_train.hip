@@ -212,6 +212,46 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     double totc[VEC], totg[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) { totc[c] = 0.0; totg[c] = 0.0; }
+    float ga = 0.0f;
+    constexpr int kHeld = 8;                       // variables up to this degree keep their rows in registers
+    if (dv <= kHeld) {
+        Pack<float, VEC> cv[kHeld], gv[kHeld];
+        size_t row[kHeld];
+#pragma unroll
+        for (int k = 0; k < kHeld; ++k) {
+            if (k < dv) {
+                row[k] = base + (size_t)g.csc_edge[k0 + k] * W;
+                cv[k] = ld<float, VEC>(c2v_prev + row[k]);
+                gv[k] = ld<float, VEC>(gv2c + row[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kHeld; ++k) {
+            if (k < dv) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c)
+                    if (state[c] != 0) { totc[c] += (double)cv[k].x[c]; totg[c] += (double)gv[k].x[c]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kHeld; ++k) {
+            if (k < dv) {
+                Pack<float, VEC> o;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    o.x[c] = 0.0f;
+                    if (state[c] != 0) {
+                        ga += gv[k].x[c] * (float)(totc[c] - (double)cv[k].x[c]);
+                        o.x[c] = alpha * (float)(totg[c] - (double)gv[k].x[c]);
+                    }
+                }
+                st<float, VEC>(gc2v_out + row[k], o);
+            }
+        }
+        ga = wave_sum(ga);
+        if (lane == 0) galpha_part[(size_t)tile * g.n + j] = ga;
+        return;
+    }
 #pragma unroll 4
     for (int k = 0; k < dv; ++k) {
         const size_t row = base + (size_t)g.csc_edge[k0 + k] * W;
@@ -221,7 +261,6 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
         for (int c = 0; c < VEC; ++c)
             if (state[c] != 0) { totc[c] += (double)cv.x[c]; totg[c] += (double)gv.x[c]; }
     }
-    float ga = 0.0f;
 #pragma unroll 4
     for (int k = 0; k < dv; ++k) {
         const size_t row = base + (size_t)g.csc_edge[k0 + k] * W;
@@ -242,17 +281,36 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     if (lane == 0) galpha_part[(size_t)tile * g.n + j] = ga;
 }
 
-// grad_table[t][slot(x)] += sum over tiles of part[t][tile][x]   (x = edge for beta, variable for alpha)
-__global__ void reduce_table_grads(const float *__restrict__ part, int T, int tiles, int count,
-                                   const int *__restrict__ slot, int n_slots, float *__restrict__ grad)
+// grad_table[t][slot(x)] += sum over tiles of part[t][tile][x]   (x = edge for beta, variable for alpha);
+// grid = (ceil(count / 256), T).  Degree-shared tables have a handful of slots: the block first gathers its 256
+// sums per slot in LDS, then issues one global atomic per slot it touched.
+constexpr int kReduceLdsSlots = 1024;
+__global__ __launch_bounds__(256) void reduce_table_grads(const float *__restrict__ part, int tiles, int count,
+                                                          const int *__restrict__ slot, int n_slots,
+                                                          float *__restrict__ grad)
 {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)T * count) return;
-    const int t = (int)(gid / count), x = (int)(gid % count);
-    const float *p = part + ((size_t)t * tiles) * count + x;
-    double s = 0.0;
-    for (int k = 0; k < tiles; ++k) s += (double)p[(size_t)k * count];
-    if (s != 0.0) atomicAdd(&grad[(size_t)t * n_slots + slot[x]], (float)s);
+    __shared__ float acc[kReduceLdsSlots];
+    const int t = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_lds = n_slots <= kReduceLdsSlots;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < n_slots; k += blockDim.x) acc[k] = 0.0f;
+        __syncthreads();
+    }
+    if (x < count) {
+        const float *p = part + ((size_t)t * tiles) * count + x;
+        double s = 0.0;
+        for (int k = 0; k < tiles; ++k) s += (double)p[(size_t)k * count];
+        if (s != 0.0) {
+            if (in_lds) atomicAdd(&acc[slot[x]], (float)s);
+            else atomicAdd(&grad[(size_t)t * n_slots + slot[x]], (float)s);
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < n_slots; k += blockDim.x)
+            if (acc[k] != 0.0f) atomicAdd(&grad[(size_t)t * n_slots + k], acc[k]);
+    }
 }
 
 }  // namespace ldpc

@@ -234,6 +234,30 @@ class DecodeEngine:
             raise ValueError(f"llr must have shape [B, {self.graph.n}], got {tuple(llr.shape)}")
         return llr.contiguous()
 
+    # saved-message buffers are GBs: one is kept for reuse (handed back by recycle_saved after backward) instead
+    # of going through the allocator every training step; the scratch of the training calls is cached like _ws
+    def _take_saved(self, nbytes: int) -> torch.Tensor:
+        buf = getattr(self, "_saved_spare", None)
+        self._saved_spare = None
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return buf
+
+    def recycle_saved(self, saved: torch.Tensor):
+        """give a saved-state buffer back once its backward has run (stream-ordered reuse on the current stream)"""
+        spare = getattr(self, "_saved_spare", None)
+        if spare is None or spare.numel() < saved.numel():
+            self._saved_spare = saved
+
+    def _train_workspace(self, batch: int) -> torch.Tensor:
+        need = int(self._lib.ldpc_train_workspace_bytes(self.handle, batch))
+        ws = getattr(self, "_train_ws", None)
+        if ws is None or ws.numel() < need:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._train_ws
+
     def train_saved_bytes(self, batch: int) -> int:
         return int(self._lib.ldpc_train_saved_bytes(self.handle, max(int(batch), 1)))
 
@@ -247,9 +271,9 @@ class DecodeEngine:
         post = torch.empty((B, n), dtype=self.dtype, device=dev)
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
         succ = torch.empty((B,), dtype=torch.uint8, device=dev)
-        saved = torch.empty(int(self._lib.ldpc_train_saved_bytes(self.handle, max(B, 1))), dtype=torch.uint8, device=dev)
+        saved = self._take_saved(int(self._lib.ldpc_train_saved_bytes(self.handle, max(B, 1))))
         if B > 0:
-            ws = torch.empty(int(self._lib.ldpc_train_workspace_bytes(self.handle, B)), dtype=torch.uint8, device=dev)
+            ws = self._train_workspace(B)
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 p = lambda t: C.c_void_p(t.data_ptr())
@@ -274,7 +298,7 @@ class DecodeEngine:
         gb = torch.zeros(self._table_shapes[0], dtype=torch.float32, device=dev)
         ga = torch.zeros(self._table_shapes[1], dtype=torch.float32, device=dev)
         if B > 0:
-            ws = torch.empty(int(self._lib.ldpc_train_workspace_bytes(self.handle, B)), dtype=torch.uint8, device=dev)
+            ws = self._train_workspace(B)
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 p = lambda t: C.c_void_p(t.data_ptr())

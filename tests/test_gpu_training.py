@@ -244,3 +244,33 @@ def test_zero_iterations_and_empty_batch(gpu_device):
     if post.requires_grad:
         post.sum().backward()
         assert all(float(p.grad.abs().sum()) == 0.0 for p in dec3.parameters() if p.grad is not None)
+
+
+def test_second_backward_needs_recycling_off(gpu_device):
+    import autograd_bridge as ab
+    from ldpc_decoder import create_test_ldpc_code
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    code = create_test_ldpc_code()
+    dec = Neural2DMinSumDecoder(code, 2, 4)
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.fill_(0.8)
+    x = torch.randn(9, code.n, device=gpu_device) + 1.0
+    _, post, _ = dec(x)
+    loss = codeword_loss_sum(post)
+    loss.backward(retain_graph=True)
+    g1 = param_grads(dec.beta_weights)
+    with pytest.raises(RuntimeError, match="RECYCLE_SAVED"):
+        loss.backward()
+    ab.RECYCLE_SAVED = False
+    try:
+        dec.zero_grad()
+        _, post, _ = dec(x)
+        loss = codeword_loss_sum(post)
+        loss.backward(retain_graph=True)
+        loss.backward()                                   # accumulates: twice the gradient
+        g2 = param_grads(dec.beta_weights)
+        for k in g1:
+            assert g2[k] == pytest.approx(2 * g1[k], rel=1e-5, abs=1e-7)
+    finally:
+        ab.RECYCLE_SAVED = True
