@@ -25,7 +25,7 @@ logger = logging.getLogger(__name__)
 
 # forward state kept for backward is (2T-1)*E*4 bytes per codeword; above this many bytes the decoders
 # return a posterior without grad_fn (and say so once) instead of exhausting HBM
-MAX_SAVED_BYTES = int(os.environ.get("LDPC_TRAIN_MAX_SAVED_BYTES", str(64 << 30)))
+MAX_SAVED_BYTES = int(os.environ.get("LDPC_TRAIN_MAX_SAVED_BYTES", str(8 << 30)))
 _warned = False
 RECYCLE_SAVED = True        # release the saved messages to the engine's spare slot after backward (see backward())
 

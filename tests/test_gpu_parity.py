@@ -65,8 +65,13 @@ def assert_post(a, b, what=""):
 def check_neural(dec, sub, gpu):
     """batched + single-vector forward against a golden block"""
     llr = torch.from_numpy(sub["llr"])
-    bits, post, iters = dec(llr.to(gpu))
+    with torch.no_grad():                       # inference: the engine LDPC_ENGINE_MODE selects
+        bits, post, iters = dec(llr.to(gpu))
     assert bits.dtype == torch.int32 and post.dtype == torch.float32 and iters.dtype == torch.int32
+    if any(p.requires_grad for p in dec.parameters()):
+        # grad enabled (the reference's default call): same numbers; the normalised min-sum decoders attach a grad_fn
+        b2, p2, i2 = dec(llr.to(gpu))
+        assert torch.equal(b2, bits) and torch.equal(i2, iters) and torch.equal(p2.detach(), post)
     np.testing.assert_array_equal(iters.cpu().numpy(), sub["iters"])
     np.testing.assert_array_equal(bits.cpu().numpy(), sub["bits"].astype(np.int32))
     assert_post(post.cpu().numpy(), sub["posterior"])

@@ -6,6 +6,7 @@ Prints one JSON line: codewords/s of forward+backward, the split, and the algori
 sweeps (per codeword and iteration: check pass reads v2c 4E + gradient 4E, writes 4E; variable pass reads c2v 4E +
 gradient 4E twice (two passes), writes 4E)."""
 import argparse, json, os, sys
+os.environ.setdefault("LDPC_TRAIN_MAX_SAVED_BYTES", str(64 << 30))     # 500 KB of messages per codeword at T = 10
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (puts the package on sys.path)
