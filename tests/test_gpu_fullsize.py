@@ -53,7 +53,7 @@ def syndrome_ok(graph, bits):
     if not isinstance(bits, torch.Tensor):
         return ~(graph.syndrome(bits).any(axis=-1))
     H = dense_H(graph, bits.device)
-    return (~torch.remainder(bits.float() @ H.T, 2).bool().any(dim=1)).cpu().numpy()
+    return (~torch.remainder(bits.float() @ H.T, 2).bool().any(dim=1)).detach().cpu().numpy()
 
 
 def test_basic_65536_rows_match_oracle_and_properties(gpu_device, oracle_mod):
@@ -71,9 +71,9 @@ def test_basic_65536_rows_match_oracle_and_properties(gpu_device, oracle_mod):
     rows = np.unique(np.r_[0, 255, 256, B - 1, rng.integers(0, B, 120)])
     for early in (True, False):
         res = eng.decode(llr, early_stop=early, want_packed=True)
-        bits = res.bits.cpu().numpy()
-        iters = res.iterations.cpu().numpy()
-        succ = res.success.cpu().numpy()
+        bits = res.bits.detach().cpu().numpy()
+        iters = res.iterations.detach().cpu().numpy()
+        succ = res.success.detach().cpu().numpy()
         assert iters.min() >= 1 and iters.max() <= 10
         if early:
             assert len(np.unique(iters)) >= 4                    # codewords of one wave stop at different times
@@ -82,12 +82,12 @@ def test_basic_65536_rows_match_oracle_and_properties(gpu_device, oracle_mod):
         else:
             assert np.all(iters == 10)
             np.testing.assert_array_equal(succ, syndrome_ok(g, res.bits))
-        ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr[rows].cpu().numpy(), 0.7, 10, early_stop=early, dtype=np.float32)
+        ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr[rows].detach().cpu().numpy(), 0.7, 10, early_stop=early, dtype=np.float32)
         np.testing.assert_array_equal(bits[rows], ob)
         np.testing.assert_array_equal(iters[rows], oi)
         np.testing.assert_array_equal(succ[rows], os_)
-        np.testing.assert_allclose(res.posterior[rows].cpu().numpy(), op, rtol=1e-5, atol=1e-5)
-        packed = res.packed_bits.cpu().numpy()
+        np.testing.assert_allclose(res.posterior[rows].detach().cpu().numpy(), op, rtol=1e-5, atol=1e-5)
+        packed = res.packed_bits.detach().cpu().numpy()
         unpacked = ((packed[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :g.n]
         np.testing.assert_array_equal(unpacked, bits)
 
@@ -149,14 +149,14 @@ def test_dvbs2_wrcq_32768_properties(gpu_device, oracle_mod):
     eng = dec._get_engine(gpu_device)
     llr = torch.cat([awgn_gpu(B // 2, g.n, 2.0, 7, gpu_device), awgn_gpu(B // 2, g.n, 5.0, 8, gpu_device)])
     res = eng.decode(llr, early_stop=True)
-    iters = res.iterations.cpu().numpy()
-    succ = res.success.cpu().numpy()
+    iters = res.iterations.detach().cpu().numpy()
+    succ = res.success.detach().cpu().numpy()
     assert iters.min() >= 1 and iters.max() <= 20
     rows = np.r_[0, B // 2 - 1, B // 2, B - 1, np.random.default_rng(1).integers(0, B, 12)]
-    bits = res.bits[rows].cpu().numpy()
+    bits = res.bits[rows].detach().cpu().numpy()
     np.testing.assert_array_equal(succ[rows], syndrome_ok(g, bits))
     og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
-    ob, op, oi, _ = oracle_mod.weighted_rcq(og, llr[rows].cpu().numpy(), 3, QP, 2, 20, beta, alpha)
+    ob, op, oi, _ = oracle_mod.weighted_rcq(og, llr[rows].detach().cpu().numpy(), 3, QP, 2, 20, beta, alpha)
     np.testing.assert_array_equal(bits, ob)
     np.testing.assert_array_equal(iters[rows], oi)
-    np.testing.assert_array_equal(res.posterior[rows].cpu().numpy(), op)
+    np.testing.assert_array_equal(res.posterior[rows].detach().cpu().numpy(), op)

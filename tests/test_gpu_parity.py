@@ -31,7 +31,7 @@ def codes_of(engine, batch):
     """per-edge quantiser codes are observable only in the streaming engine's HBM state"""
     if engine.info()["engine"] != "stream":
         return None
-    return engine.debug_c2v(batch).cpu().numpy()
+    return engine.debug_c2v(batch).detach().cpu().numpy()
 
 
 # --------------------------------------------------------------------------------- helpers
@@ -72,15 +72,15 @@ def check_neural(dec, sub, gpu):
         # grad enabled (the reference's default call): same numbers; the normalised min-sum decoders attach a grad_fn
         b2, p2, i2 = dec(llr.to(gpu))
         assert torch.equal(b2, bits) and torch.equal(i2, iters) and torch.equal(p2.detach(), post)
-    np.testing.assert_array_equal(iters.cpu().numpy(), sub["iters"])
-    np.testing.assert_array_equal(bits.cpu().numpy(), sub["bits"].astype(np.int32))
-    assert_post(post.cpu().numpy(), sub["posterior"])
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), sub["iters"])
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), sub["bits"].astype(np.int32))
+    assert_post(post.detach().cpu().numpy(), sub["posterior"])
     # the reference's own call shape: one CPU vector in, CPU tensors + python int out
     b1, p1, i1 = dec(llr[0])
     assert b1.device.type == "cpu" and b1.shape == (dec.code.n,) and isinstance(i1, int)
     assert i1 == int(sub["iters"][0])
     np.testing.assert_array_equal(b1.numpy(), sub["bits"][0].astype(np.int32))
-    assert_post(p1.numpy(), sub["posterior"][0])
+    assert_post(p1.detach().numpy(), sub["posterior"][0])
 
 
 def final_codes(golden_codes, iters):
@@ -165,9 +165,9 @@ def check_rcq(code, sub, gpu, bc=3, qp=QP):
     dec = RCQMinSumDecoder(code, bc=bc, bv=8, quantizer_params=qp, max_iterations=int(sub["T"]))
     llr = torch.from_numpy(sub["llr"])
     bits, succ, iters = dec.decode(llr.to(gpu))
-    np.testing.assert_array_equal(iters.cpu().numpy(), sub["iters"])
-    np.testing.assert_array_equal(succ.cpu().numpy(), sub["success"])
-    np.testing.assert_array_equal(bits.cpu().numpy(), sub["bits"].astype(np.int32))
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), sub["iters"])
+    np.testing.assert_array_equal(succ.detach().cpu().numpy(), sub["success"])
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), sub["bits"].astype(np.int32))
     # per-edge quantiser codes (CSR order) of every codeword's last executed iteration
     codes = codes_of(dec._engine, len(llr))
     if codes is not None:
@@ -190,7 +190,7 @@ def check_wrcq(code, sub, gpu, wtype, bc=3, qp=QP):
         np.testing.assert_array_equal(codes, final_codes(sub["codes"], sub["iters"]))
     # RCQ posteriors are sums of a handful of table values: must be equal as values
     b, p, i = dec(torch.from_numpy(sub["llr"]).to(gpu))
-    np.testing.assert_array_equal(p.cpu().numpy(), sub["posterior"])
+    np.testing.assert_array_equal(p.detach().cpu().numpy(), sub["posterior"])
 
 
 def test_rcq_toy_golden(gpu_device):
@@ -260,9 +260,9 @@ def test_batch_sizes_vs_oracle_neural2d(B, early_stop, gpu_device, oracle_mod):
     bits, post, iters = dec(torch.from_numpy(llr).to(gpu_device), early_stop=early_stop)
     og = oracle_mod.OracleGraph(code.H)
     ob, op, oi, _ = oracle_mod.neural2d(og, llr, 2, 8, beta, alpha, early_stop=early_stop)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-    assert_post(post.cpu().numpy(), op)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+    assert_post(post.detach().cpu().numpy(), op)
 
 
 @pytest.mark.parametrize("early_stop", [True, False])
@@ -280,25 +280,25 @@ def test_ira_batch_vs_oracle_all_decoders(early_stop, gpu_device, oracle_mod):
 
     bits, succ, iters = BasicMinSumDecoder(code).decode(x, early_stop=early_stop)
     ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr, 0.7, 10, early_stop=early_stop, dtype=np.float32)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.detach().cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
 
     for wtype in (1, 2, 4):
         dec = Neural2DMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=10)
         beta, alpha = rand_weights(dec, rng)
         bits, post, iters = dec(x, early_stop=early_stop)
         ob, op, oi, _ = oracle_mod.neural2d(og, llr, wtype, 10, beta, alpha, early_stop=early_stop)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        assert_post(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        assert_post(post.detach().cpu().numpy(), op)
 
     dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=10)
     bits, succ, iters = dec.decode(x, early_stop=early_stop)
     ob, op, oi, os_, oc = oracle_mod.rcq(og, llr, 3, QP, 10, early_stop=early_stop, trace_codes=True)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.detach().cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
     if codes_of(dec._engine, B) is not None:
         np.testing.assert_array_equal(codes_of(dec._engine, B), final_codes(oc, oi))
 
@@ -306,9 +306,9 @@ def test_ira_batch_vs_oracle_all_decoders(early_stop, gpu_device, oracle_mod):
     beta, alpha = rand_weights(dec, rng)
     bits, post, iters = dec(x, early_stop=early_stop)
     ob, op, oi, _, oc = oracle_mod.weighted_rcq(og, llr, 3, QP, 2, 10, beta, alpha, early_stop=early_stop, trace_codes=True)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-    np.testing.assert_array_equal(post.cpu().numpy(), op)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+    np.testing.assert_array_equal(post.detach().cpu().numpy(), op)
     if codes_of(dec._engine, B) is not None:
         np.testing.assert_array_equal(codes_of(dec._engine, B), final_codes(oc, oi))
 
@@ -337,9 +337,9 @@ def test_offset_minsum_vs_oracle(gpu_device, oracle_mod):
         ob, op, oi, _ = oracle_mod.decode(og, llr, T=7, c2v_form=oracle_mod.C2V_OMS, beta=bt, beta_slot=lay.beta_slot,
                                           alpha=np.ones((7, 1), np.float32), alpha_slot=np.zeros(96, np.int32),
                                           oms_alpha=at, oms_alpha_slot=lay.alpha_edge_slot)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        assert_post(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        assert_post(post.detach().cpu().numpy(), op)
 
 
 @pytest.mark.parametrize("name", ["toy_offset_edge", "small_offset_edge"])
@@ -402,15 +402,15 @@ def test_odd_degrees_and_iteration_counts(T, gpu_device, oracle_mod):
     beta, alpha = rand_weights(dec, rng)
     bits, post, iters = dec(x)
     ob, op, oi, _ = oracle_mod.neural2d(og, llr, 1, T, beta, alpha)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-    assert_post(post.cpu().numpy(), op)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+    assert_post(post.detach().cpu().numpy(), op)
     dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=T)
     bits, succ, iters = dec.decode(x)
     ob, op, oi, os_ = oracle_mod.rcq(og, llr, 3, QP, T)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.detach().cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
 
 
 def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
@@ -426,9 +426,9 @@ def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
         dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=int(g[f"{tag}_T"]), layered=True)
         llr = torch.from_numpy(g[f"{tag}_llr"])
         bits, succ, iters = dec.decode(llr.to(gpu_device))
-        np.testing.assert_array_equal(iters.cpu().numpy(), g[f"{tag}_iters"])
-        np.testing.assert_array_equal(succ.cpu().numpy(), g[f"{tag}_success"])
-        np.testing.assert_array_equal(bits.cpu().numpy(), g[f"{tag}_bits"].astype(np.int32))
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), g[f"{tag}_iters"])
+        np.testing.assert_array_equal(succ.detach().cpu().numpy(), g[f"{tag}_success"])
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), g[f"{tag}_bits"].astype(np.int32))
         b1, s1, i1 = dec.decode(llr[3])
         assert isinstance(s1, bool) and (s1, i1) == (bool(g[f"{tag}_success"][3]), int(g[f"{tag}_iters"][3]))
         np.testing.assert_array_equal(b1.numpy(), g[f"{tag}_bits"][3].astype(np.int32))
@@ -440,11 +440,11 @@ def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
     dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=10, layered=True)
     bits, succ, iters = dec.decode(torch.from_numpy(llr).to(gpu_device))
     ob, op, oi, os_ = oracle_mod.rcq_layered(og, llr, 3, QP, 10)
-    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
-    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.detach().cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
     res = dec._engine.decode(torch.from_numpy(llr).to(gpu_device), early_stop=True)
-    np.testing.assert_array_equal(res.posterior.cpu().numpy(), op)          # latched posteriors, value-equal
+    np.testing.assert_array_equal(res.posterior.detach().cpu().numpy(), op)          # latched posteriors, value-equal
     assert len(np.unique(oi)) >= 2                                          # early stop was exercised
 
 
@@ -486,22 +486,22 @@ def test_resident_engine_edge_cases(T, B, gpu_device, oracle_mod, engine_mode):
         if engine_mode == "auto":
             assert dec._engine.info()["engine"] == "resident"
         ob, op, oi, _ = oracle_mod.neural2d(og, llr, 1, T, beta, alpha, early_stop=early)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        assert_post(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        assert_post(post.detach().cpu().numpy(), op)
         res = dec._engine.decode(x, early_stop=early, want_packed=True)
         osucc = oracle_mod.neural2d(og, llr, 1, T, beta, alpha, early_stop=early)[3]
-        np.testing.assert_array_equal(res.success.cpu().numpy(), osucc)
-        unpacked = ((res.packed_bits.cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :40]
+        np.testing.assert_array_equal(res.success.detach().cpu().numpy(), osucc)
+        unpacked = ((res.packed_bits.detach().cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :40]
         np.testing.assert_array_equal(unpacked, ob)
 
         w = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=2, max_iterations=T)
         beta, alpha = rand_weights(w, rng)
         bits, post, iters = w(x, early_stop=early)
         ob, op, oi, _ = oracle_mod.weighted_rcq(og, llr, 3, QP, 2, T, beta, alpha, early_stop=early)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        np.testing.assert_array_equal(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        np.testing.assert_array_equal(post.detach().cpu().numpy(), op)
 
         o = Neural2DOffsetMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
         with torch.no_grad():
@@ -512,9 +512,9 @@ def test_resident_engine_edge_cases(T, B, gpu_device, oracle_mod, engine_mode):
         bits, post, iters = o(x, early_stop=early)
         ob, op, oi, _ = oracle_mod.neural2d_offset(og, llr, 2, T, {k: float(v.item()) for k, v in o.beta_weights.items()},
                                                    {k: float(v.item()) for k, v in o.alpha_weights.items()}, early_stop=early)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        assert_post(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        assert_post(post.detach().cpu().numpy(), op)
 
 
 def test_error_behaviour(gpu_device):
@@ -551,9 +551,9 @@ def test_weight_update_is_picked_up(gpu_device, oracle_mod):
         beta, alpha = rand_weights(dec, rng)
         bits, post, iters = dec(x)
         ob, op, oi, _ = oracle_mod.neural2d(og, llr, 2, 6, beta, alpha)
-        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
-        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
-        assert_post(post.cpu().numpy(), op)
+        np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
+        np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
+        assert_post(post.detach().cpu().numpy(), op)
 
 
 def test_packed_bits_and_threads(gpu_device):
@@ -568,13 +568,13 @@ def test_packed_bits_and_threads(gpu_device):
     dec = RCQMinSumDecoder(code, 3, 8, QP, 10)
     ref_bits, _, _ = dec.decode(llr)
     res = dec._engine.decode(llr, want_packed=True, want_posterior=False)
-    unpacked = ((res.packed_bits.cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(500, -1)[:, :96]
-    np.testing.assert_array_equal(unpacked, ref_bits.cpu().numpy())
+    unpacked = ((res.packed_bits.detach().cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(500, -1)[:, :96]
+    np.testing.assert_array_equal(unpacked, ref_bits.detach().cpu().numpy())
 
     def work(seed):
         d = RCQMinSumDecoder(code, 3, 8, QP, 10)
-        return d.decode(llr)[0].cpu().numpy()
+        return d.decode(llr)[0].detach().cpu().numpy()
     with ThreadPoolExecutor(4) as ex:
         outs = list(ex.map(work, range(4)))
     for o in outs:
-        np.testing.assert_array_equal(o, ref_bits.cpu().numpy())
+        np.testing.assert_array_equal(o, ref_bits.detach().cpu().numpy())
