@@ -49,17 +49,27 @@ def saved_state_fits(engine, batch: int) -> bool:
 
 
 class MinSumDecodeFn(torch.autograd.Function):
-    """(beta_table [T, Sb], alpha_table [T, Sa]) -> posterior [B, n]; bits and iterations ride along"""
+    """(beta_table [T, Sb], alpha_table [T, Sa]) -> posterior [B, n]; bits and iterations ride along.
+    `alpha_is_oms`: the alpha table is the check-side offset of the offset decoders (engine slot oms_alpha),
+    otherwise the variable-side multiplier (engine slot alpha)."""
 
     @staticmethod
-    def forward(ctx, beta_table, alpha_table, engine, xd, early_stop):
+    def forward(ctx, beta_table, alpha_table, engine, xd, early_stop, alpha_is_oms=False):
         res, saved = engine.decode_saving(xd, early_stop=early_stop)
         ctx.engine, ctx.saved, ctx.xd, ctx.iters = engine, saved, xd, res.iterations
+        ctx.alpha_is_oms = bool(alpha_is_oms)
         ctx.tables = (beta_table.detach().to("cpu", torch.float32).numpy().copy(),
                       alpha_table.detach().to("cpu", torch.float32).numpy().copy())
         ctx.meta = (beta_table.device, beta_table.dtype, alpha_table.device, alpha_table.dtype)
         ctx.mark_non_differentiable(res.bits, res.iterations)
         return res.posterior, res.bits, res.iterations
+
+    @staticmethod
+    def _upload(eng, beta, alpha, alpha_is_oms):
+        if alpha_is_oms:
+            eng.set_weights(beta, None, alpha if eng.current_tables()[2] is not None else None)
+        else:
+            eng.set_weights(beta, alpha)
 
     @staticmethod
     def backward(ctx, g_post, _g_bits, _g_iters):
@@ -68,19 +78,22 @@ class MinSumDecodeFn(torch.autograd.Function):
             raise RuntimeError("the saved messages of this decode were released by its first backward; for "
                                "backward(retain_graph=True) set autograd_bridge.RECYCLE_SAVED = False")
         held = eng.current_tables()
-        same = np.array_equal(held[0], ctx.tables[0]) and np.array_equal(held[1], ctx.tables[1])
+        held_alpha = held[2] if ctx.alpha_is_oms else held[1]
+        same = np.array_equal(held[0], ctx.tables[0]) and (held_alpha is None or np.array_equal(held_alpha, ctx.tables[1]))
         if not same:                       # the weights moved on since this forward: put its tables back for the sweep
-            eng.set_weights(ctx.tables[0], ctx.tables[1])
+            MinSumDecodeFn._upload(eng, ctx.tables[0], ctx.tables[1], ctx.alpha_is_oms)
         try:
-            gb, ga = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post)
+            gb, ga, goa = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post)
         finally:
             if not same:
-                eng.set_weights(held[0], held[1])
+                MinSumDecodeFn._upload(eng, held[0], held_alpha, ctx.alpha_is_oms)
         if RECYCLE_SAVED:                  # GBs of messages: hand the buffer to the next forward instead of the allocator
             eng.recycle_saved(ctx.saved)
             ctx.saved = None
+        if ctx.alpha_is_oms:
+            ga = goa if goa is not None else torch.zeros(ctx.tables[1].shape, dtype=torch.float32, device=gb.device)
         bdev, bdt, adev, adt = ctx.meta
-        return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None
+        return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None, None
 
 
 def table_from_params(params, where, shape, default: float) -> torch.Tensor:

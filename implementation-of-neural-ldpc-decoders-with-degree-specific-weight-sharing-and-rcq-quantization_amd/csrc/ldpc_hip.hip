@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <vector>
 
@@ -605,8 +606,20 @@ extern "C" {
 const char *ldpc_last_error(void) { return g_err; }
 int ldpc_abi_version(void) { return LDPC_HIP_ABI_VERSION; }
 
-int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const int32_t *check_ptr,
-                      const int32_t *var_idx)
+// Host-side containers may throw; no exception crosses the C boundary.
+#define LDPC_NOTHROW(call)                                                                     \
+    try {                                                                                      \
+        return call;                                                                           \
+    } catch (const std::bad_alloc &) {                                                         \
+        return fail(LDPC_ERR_HIP, "out of host memory");                                       \
+    } catch (const std::exception &e) {                                                        \
+        return fail(LDPC_ERR_HIP, "internal error: %s", e.what());                             \
+    } catch (...) {                                                                            \
+        return fail(LDPC_ERR_HIP, "internal error");                                           \
+    }
+
+static int graph_create_impl(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const int32_t *check_ptr,
+                             const int32_t *var_idx)
 {
     if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -662,6 +675,12 @@ int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const i
     return LDPC_OK;
 }
 
+int ldpc_graph_create(ldpc_graph **out, int32_t n, int32_t m, int32_t E, const int32_t *check_ptr,
+                      const int32_t *var_idx)
+{
+    LDPC_NOTHROW(graph_create_impl(out, n, m, E, check_ptr, var_idx))
+}
+
 void ldpc_graph_destroy(ldpc_graph *g)
 {
     if (!g) return;
@@ -677,7 +696,7 @@ int ldpc_graph_info(const ldpc_graph *g, int32_t out5[5])
     return LDPC_OK;
 }
 
-int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc)
+static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc)
 {
     if (!out) return fail(LDPC_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -768,6 +787,11 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
     }
     *out = d;
     return LDPC_OK;
+}
+
+int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc)
+{
+    LDPC_NOTHROW(decoder_create_impl(out, g, desc))
 }
 
 int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
@@ -875,15 +899,16 @@ namespace {
 int train_supported(const ldpc_decoder *d)
 {
     if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
-    if (d->dtype != LDPC_F32 || d->form != LDPC_C2V_NMS || d->schedule != LDPC_SCHED_FLOODING)
-        return fail(LDPC_ERR_UNSUPPORTED, "gradients exist for fp32 normalised min-sum flooding decoders only "
-                                          "(the RCQ quantiser and the offset form's relu are not trained by the reference)");
+    if (d->dtype != LDPC_F32 || d->form == LDPC_C2V_RCQ || d->schedule != LDPC_SCHED_FLOODING)
+        return fail(LDPC_ERR_UNSUPPORTED, "gradients exist for the fp32 normalised / offset min-sum flooding decoders "
+                                          "(the reference's RCQ quantiser passes no gradient)");
     return LDPC_OK;
 }
 
 struct BackwardWs {
     int vec = 0, tiles = 0;
     float *llrT = nullptr, *gpostT = nullptr, *gv2c = nullptr, *gc2v = nullptr, *gbeta = nullptr, *galpha = nullptr;
+    float *goa = nullptr;             // offset form: per-edge partials of the check-side alpha
     size_t part_bytes = 0, total = 0;
 };
 BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
@@ -897,19 +922,22 @@ BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_llr = take(tw * n * 4), o_gp = take(tw * n * 4), o_gv = take(tw * E * 4), o_gc = take(tw * E * 4);
     const size_t o_gb = take(T * w.tiles * E * 4), o_ga = take(T * w.tiles * n * 4);
+    const size_t o_goa = take(d->form == LDPC_C2V_OMS ? T * w.tiles * E * 4 : 0);
     w.part_bytes = off - o_gb;
     w.total = off;
     if (base) {
         char *b = (char *)base;
         w.llrT = (float *)(b + o_llr); w.gpostT = (float *)(b + o_gp); w.gv2c = (float *)(b + o_gv);
         w.gc2v = (float *)(b + o_gc); w.gbeta = (float *)(b + o_gb); w.galpha = (float *)(b + o_ga);
+        w.goa = (float *)(b + o_goa);
     }
     return w;
 }
 
 template <int VEC>
 int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, int64_t batch, const int32_t *iterations,
-                  const float *grad_posterior, float *grad_beta, float *grad_alpha, const BackwardWs &w, hipStream_t s)
+                  const float *grad_posterior, float *grad_beta, float *grad_alpha, float *grad_oms_alpha,
+                  const BackwardWs &w, hipStream_t s)
 {
     constexpr int W = 64 * VEC;
     constexpr int JT = 32;
@@ -926,25 +954,34 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     for (int t = T - 1; t >= 0; --t) {
         const float *beta_row = (const float *)d->beta + (size_t)t * d->n_beta;
         // d loss/d c2v_t is in w.gc2v (written by the variable pass of step t+1; unread at t == T-1)
+        const bool oms = d->form == LDPC_C2V_OMS;
+        float *goa = (oms && d->oms_alpha) ? w.goa + (size_t)t * epart : nullptr;
+#define LDPC_CNB(FIRST_, FORM_, SRC_, OUT_)                                                                            \
+    hipLaunchKernelGGL((cn_backward<VEC, FIRST_, FORM_>), cgrid, blk, 0, s, g, (const float *)(SRC_),                  \
+                       (const float *)w.gc2v, (const float *)w.gpostT, iterations, (long long)batch, t, beta_row,     \
+                       (const int *)d->beta_slot, (float *)(OUT_), w.gbeta + (size_t)t * epart, goa, cb)
         if (t == 0) {
-            hipLaunchKernelGGL((cn_backward<VEC, true>), cgrid, blk, 0, s, g, (const float *)w.llrT, (const float *)w.gc2v,
-                               (const float *)w.gpostT, iterations, (long long)batch, t, beta_row, (const int *)d->beta_slot,
-                               (float *)nullptr, w.gbeta + (size_t)t * epart, cb);
+            if (oms) LDPC_CNB(true, FORM_OMS, w.llrT, nullptr); else LDPC_CNB(true, FORM_NMS, w.llrT, nullptr);
         } else {
-            hipLaunchKernelGGL((cn_backward<VEC, false>), cgrid, blk, 0, s, g, (const float *)(saved + sl.v2c_off(t)),
-                               (const float *)w.gc2v, (const float *)w.gpostT, iterations, (long long)batch, t, beta_row,
-                               (const int *)d->beta_slot, w.gv2c, w.gbeta + (size_t)t * epart, cb);
+            if (oms) LDPC_CNB(false, FORM_OMS, saved + sl.v2c_off(t), w.gv2c);
+            else LDPC_CNB(false, FORM_NMS, saved + sl.v2c_off(t), w.gv2c);
             const float *alpha_row = (const float *)d->alpha + (size_t)(t - 1) * d->n_alpha;
             hipLaunchKernelGGL((vn_backward<VEC>), vgrid, blk, 0, s, g, (const float *)(saved + sl.c2v_off(t - 1)),
                                (const float *)w.gv2c, iterations, (long long)batch, t, alpha_row, (const int *)d->alpha_slot,
                                w.gc2v, w.galpha + (size_t)(t - 1) * vpart, vb);
         }
+#undef LDPC_CNB
     }
     HIP_TRY(hipGetLastError());
     if (grad_beta) {
         HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)T * d->n_beta * 4, s));
         hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
                            (const float *)w.gbeta, w.tiles, g.E, (const int *)d->beta_slot, d->n_beta, grad_beta);
+    }
+    if (grad_oms_alpha && d->form == LDPC_C2V_OMS && d->oms_alpha) {
+        HIP_TRY(hipMemsetAsync(grad_oms_alpha, 0, (size_t)T * d->n_oms_alpha * 4, s));
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                           (const float *)w.goa, w.tiles, g.E, (const int *)d->oms_alpha_slot, d->n_oms_alpha, grad_oms_alpha);
     }
     if (grad_alpha) {
         HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)T * d->n_alpha * 4, s));
@@ -993,16 +1030,18 @@ int ldpc_decode_saving(const ldpc_decoder *d, const void *llr, int64_t batch, in
 
 int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, const void *llr, int64_t batch,
                   const int32_t *iterations, const void *grad_posterior, void *grad_beta, void *grad_alpha,
-                  void *workspace, size_t workspace_bytes, void *stream)
+                  void *grad_oms_alpha, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = train_supported(d)) return rc;
     if (batch < 0) return fail(LDPC_ERR_ARG, "batch < 0");
-    if (!grad_beta && !grad_alpha) return LDPC_OK;
+    if (!grad_beta && !grad_alpha && !grad_oms_alpha) return LDPC_OK;
     DeviceGuard guard(d->g->device);
     hipStream_t s = (hipStream_t)stream;
     if (batch == 0 || d->g->n == 0 || d->T == 0 || d->g->E == 0) {       // no iteration ran: the posterior is the LLR
         if (grad_beta) HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)std::max(d->T, 1) * d->n_beta * 4, s));
         if (grad_alpha) HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)std::max(d->T, 1) * d->n_alpha * 4, s));
+        if (grad_oms_alpha && d->n_oms_alpha > 0)
+            HIP_TRY(hipMemsetAsync(grad_oms_alpha, 0, (size_t)std::max(d->T, 1) * d->n_oms_alpha * 4, s));
         return LDPC_OK;
     }
     if (!saved || !llr || !iterations || !grad_posterior || !workspace) return fail(LDPC_ERR_ARG, "NULL argument");
@@ -1014,9 +1053,9 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
     if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
     if (w.vec == 1)
         return backward_impl<1>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
-                                (float *)grad_beta, (float *)grad_alpha, w, s);
+                                (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, w, s);
     return backward_impl<4>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
-                            (float *)grad_beta, (float *)grad_alpha, w, s);
+                            (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, w, s);
 }
 
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])

@@ -48,7 +48,11 @@ __device__ __forceinline__ void load_states(const int *__restrict__ iterations, 
 // out: d loss/d v2c_t rows (not when FIRST: v2c_0 = llr has no parameters upstream),
 //      per-edge partial of d loss/d beta_t.
 // ------------------------------------------------------------------------------------------
-template <int VEC, bool FIRST>
+//
+// FORM_NMS: c2v = beta * minval * prod(signs).   FORM_OMS: c2v = prod(signs) * (relu(minval - beta) - alpha_c)
+// (neural_2d_decoder.py:389-401, neural_minsum_decoder.py:245-253): d/d beta = -g*ps*[minval > beta],
+// d/d alpha_c = -g*ps (second per-edge partial, goa_part), d/d minval = g*ps*[minval > beta]; relu'(0) = 0.
+template <int VEC, bool FIRST, int FORM>
 __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *__restrict__ src,
                                                       const float *__restrict__ gc2v,
                                                       const float *__restrict__ gpostT,
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
                                                       const float *__restrict__ beta_row,
                                                       const int *__restrict__ beta_slot,
                                                       float *__restrict__ gv2c_out,
-                                                      float *__restrict__ gbeta_part, int check_blocks)
+                                                      float *__restrict__ gbeta_part,
+                                                      float *__restrict__ goa_part, int check_blocks)
 {
     constexpr int W = kWave * VEC;
     const int lane = threadIdx.x & (kWave - 1);
@@ -84,7 +89,10 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
         for (int c = 0; c < VEC; ++c) z.x[c] = 0.0f;
         for (int u = 0; u < dc; ++u) {
             if (!FIRST) st<float, VEC>(out_base + (size_t)u * W, z);
-            if (lane == 0) gbeta_part[(size_t)tile * g.E + e0 + u] = 0.0f;
+            if (lane == 0) {
+                gbeta_part[(size_t)tile * g.E + e0 + u] = 0.0f;
+                if (FORM == FORM_OMS && goa_part) goa_part[(size_t)tile * g.E + e0 + u] = 0.0f;
+            }
         }
         return;
     }
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
         if (any_vn) gv = ld<float, VEC>(gc2v + erow + (size_t)u * W);
         if (any_post) gp = ld<float, VEC>(gpostT + ((size_t)tile * g.n + g.var_idx[e0 + u]) * W + lane_off);
         if (wide) re = ld<float, VEC>(in_row(u));
-        float gb = 0.0f;
+        float gb = 0.0f, goa = 0.0f;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const unsigned own = wide ? signbit_of<float>(re.x[c]) : ((sm[c] >> (u & 31)) & 1u);
@@ -142,13 +150,25 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
             const float minval = (u == idx[c]) ? m2[c] : m1[c];
             const float gps = gin * ps;
             if (state[c] != 0) {
-                gb += gps * minval;
-                const float gm = gps * b;
+                float gm;
+                if (FORM == FORM_OMS) {
+                    const float open = (minval - b) > 0.0f ? gps : 0.0f;      // relu gate
+                    gb -= open;
+                    goa -= gps;
+                    gm = open;
+                } else {
+                    gb += gps * minval;
+                    gm = gps * b;
+                }
                 if (u == idx[c]) acc2[c] += gm; else acc1[c] += gm;
             }
         }
         gb = wave_sum(gb);
-        if (lane == 0) gbeta_part[(size_t)tile * g.E + e0 + u] = gb;
+        if (FORM == FORM_OMS && goa_part) goa = wave_sum(goa);
+        if (lane == 0) {
+            gbeta_part[(size_t)tile * g.E + e0 + u] = gb;
+            if (FORM == FORM_OMS && goa_part) goa_part[(size_t)tile * g.E + e0 + u] = goa;
+        }
     }
     if (FIRST) return;
     for (int u = 0; u < dc; ++u) {

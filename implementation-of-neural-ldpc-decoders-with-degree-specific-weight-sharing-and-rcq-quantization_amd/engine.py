@@ -129,7 +129,8 @@ class DecodeEngine:
             desc.oms_alpha, desc.oms_alpha_slot = nat.ptr(oms_alpha), nat.ptr(oms_alpha_slot)
             keep += [oms_alpha, oms_alpha_slot]
         self._table_shapes = (beta.shape, alpha.shape, None if oms_alpha is None else oms_alpha.shape)
-        self._tables = [beta.copy(), alpha.copy()]          # what the device holds (gradient path restores them)
+        # what the device holds (the gradient path restores them): beta, alpha, check-side alpha of the offset form
+        self._tables = [beta.copy(), alpha.copy(), None if oms_alpha is None else oms_alpha.copy()]
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(lib.ldpc_decoder_create(C.byref(self.handle), self._ng.handle, C.byref(desc)),
@@ -181,10 +182,12 @@ class DecodeEngine:
             self._tables[0] = beta.copy()
         if alpha is not None:
             self._tables[1] = alpha.copy()
+        if oms_alpha is not None:
+            self._tables[2] = oms_alpha.copy()
 
     def current_tables(self):
-        """(beta [T, Sb], alpha [T, Sa]) numpy copies of the tables the device holds"""
-        return self._tables[0], self._tables[1]
+        """(beta [T, Sb], alpha [T, Sa], oms_alpha [T, So] | None) numpy copies of the tables the device holds"""
+        return tuple(self._tables)
 
     # ------------------------------------------------------------------ decode
     def workspace_bytes(self, batch: int) -> int:
@@ -283,9 +286,9 @@ class DecodeEngine:
         return DecodeResult(bits, post, iters, succ.bool(), None), saved
 
     def backward(self, saved: torch.Tensor, llr: torch.Tensor, iterations: torch.Tensor, grad_posterior: torch.Tensor):
-        """(d loss/d beta [T, beta slots], d loss/d alpha [T, alpha slots]) for a loss with
-        d loss/d posterior = grad_posterior [B, n]; `saved`, `iterations` from decode_saving of the same llr
-        with the same weight tables."""
+        """(d loss/d beta [T, beta slots], d loss/d alpha [T, alpha slots], d loss/d oms_alpha [T, slots] | None)
+        for a loss with d loss/d posterior = grad_posterior [B, n]; `saved`, `iterations` from decode_saving of the
+        same llr with the same weight tables."""
         llr = self._check_llr(llr)
         B, n = llr.shape
         dev = self.device
@@ -297,14 +300,16 @@ class DecodeEngine:
             raise ValueError("iterations must have one entry per codeword")
         gb = torch.zeros(self._table_shapes[0], dtype=torch.float32, device=dev)
         ga = torch.zeros(self._table_shapes[1], dtype=torch.float32, device=dev)
+        goa = None if self._table_shapes[2] is None else torch.zeros(self._table_shapes[2], dtype=torch.float32, device=dev)
         if B > 0:
             ws = self._train_workspace(B)
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                p = lambda t: C.c_void_p(t.data_ptr())
+                p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
                 nat.check(self._lib.ldpc_backward(self.handle, p(saved), saved.numel(), p(llr), B, p(iterations), p(gp),
-                                                  p(gb), p(ga), p(ws), ws.numel(), C.c_void_p(stream)), "ldpc_backward")
-        return gb, ga
+                                                  p(gb), p(ga), p(goa), p(ws), ws.numel(), C.c_void_p(stream)),
+                          "ldpc_backward")
+        return gb, ga, goa
 
     def debug_sweep(self, batch: int, which: int, it: int):
         """Launch one CN (which=0) or VN (which=1) sweep on the state a previous

@@ -41,6 +41,7 @@ class _DegreeSharedDecoder(nn.Module):
 
     _beta_default = 0.7
     _alpha_default = 1.0
+    _alpha_is_oms = False          # True: alpha is the check-side offset of the offset form (engine slot oms_alpha)
 
     def _init_sharing(self, code: LDPCCode, weight_sharing_type: int, max_iterations: int, strict=True):
         self.code = code
@@ -111,6 +112,26 @@ class _DegreeSharedDecoder(nn.Module):
         return res, single, llr.device
 
 
+    def _decode_with_grad(self, llr, early_stop, device):
+        """the reference's posterior carries a grad_fn back to beta/alpha (neural_2d_decoder.py:189-209);
+        here the HIP backward sweeps provide it (autograd_bridge.py)"""
+        import autograd_bridge as ab
+        if not isinstance(llr, torch.Tensor):
+            raise TypeError("llr must be a torch.Tensor")
+        _, x, single = _as_batch(llr, self.code.n)
+        eng = self._get_engine(x.device if x.is_cuda else device)       # uploads the current parameter values
+        if not ab.saved_state_fits(eng, x.shape[0]):
+            return None
+        bt, at = self._sharing_layout().tables_torch(self.beta_weights, self.alpha_weights, int(self.max_iterations),
+                                                     self._beta_default, self._alpha_default)
+        xd = x.detach().to(device=eng.device, dtype=torch.float32)
+        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop), self._alpha_is_oms)
+        out_dev = llr.device
+        if single:
+            return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
+        return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
+
+
 class Neural2DMinSumDecoder(_DegreeSharedDecoder):
     """
     Neural 2D MinSum decoder with node-degree-based weight sharing
@@ -151,25 +172,6 @@ class Neural2DMinSumDecoder(_DegreeSharedDecoder):
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())
         return res.bits.to(out_dev), res.posterior.to(out_dev), res.iterations.to(out_dev)
 
-    def _decode_with_grad(self, llr, early_stop, device):
-        """the reference's posterior carries a grad_fn back to beta/alpha (neural_2d_decoder.py:189-209);
-        here the HIP backward sweeps provide it (autograd_bridge.py)"""
-        import autograd_bridge as ab
-        if not isinstance(llr, torch.Tensor):
-            raise TypeError("llr must be a torch.Tensor")
-        _, x, single = _as_batch(llr, self.code.n)
-        eng = self._get_engine(x.device if x.is_cuda else device)       # uploads the current parameter values
-        if not ab.saved_state_fits(eng, x.shape[0]):
-            return None
-        bt, at = self._sharing_layout().tables_torch(self.beta_weights, self.alpha_weights, int(self.max_iterations),
-                                                     self._beta_default, self._alpha_default)
-        xd = x.detach().to(device=eng.device, dtype=torch.float32)
-        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop))
-        out_dev = llr.device
-        if single:
-            return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
-        return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
-
 
 class Neural2DOffsetMinSumDecoder(_DegreeSharedDecoder):
     """
@@ -179,6 +181,7 @@ class Neural2DOffsetMinSumDecoder(_DegreeSharedDecoder):
 
     _beta_default = 0.0
     _alpha_default = 0.0
+    _alpha_is_oms = True
 
     def __init__(self, code: LDPCCode, weight_sharing_type: int = 2, max_iterations: int = 50):
         super().__init__()
@@ -198,6 +201,11 @@ class Neural2DOffsetMinSumDecoder(_DegreeSharedDecoder):
         return beta, None, alpha
 
     def forward(self, llr: torch.Tensor, early_stop: bool = True, device=None):
+        import autograd_bridge as ab
+        if ab.wants_grad(self):            # relu / offset are differentiable in the reference too (:396-401)
+            out = self._decode_with_grad(llr, early_stop, device)
+            if out is not None:
+                return out
         res, single, out_dev = self._decode(llr, early_stop, device)
         if single:
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())

@@ -100,7 +100,7 @@ class _EdgeWeightDecoder(nn.Module):
         eng = self._get_engine(x.device if x.is_cuda else device)
         out_dev = llr.device
         import autograd_bridge as ab
-        if self._c2v_form == "nms" and ab.wants_grad(self) and ab.saved_state_fits(eng, x.shape[0]):
+        if ab.wants_grad(self) and ab.saved_state_fits(eng, x.shape[0]):
             # posterior with a grad_fn back to the edge weights, as in the reference (neural_minsum_decoder.py:100-139)
             g, T = self.code.tanner_graph(), int(self.max_iterations)
             rows, cols = g.check_of_edge.tolist(), g.var_idx.tolist()

@@ -150,7 +150,7 @@ int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t ou
  * Replaces torch autograd through Neural2DMinSumDecoder.forward / NeuralMinSumDecoder.forward
  * (neural_2d_decoder.py:133-225 under loss.backward(), training_framework.py:127-134): the
  * derivative of any loss of the returned posterior with respect to the beta / alpha tables.
- * fp32 normalised min-sum flooding decoders only (LDPC_ERR_UNSUPPORTED otherwise; the reference's
+ * fp32 LDPC_C2V_NMS and LDPC_C2V_OMS flooding decoders (LDPC_ERR_UNSUPPORTED otherwise; the reference's
  * RCQ quantiser passes no gradient).  Always runs the streaming engine.
  *
  * ldpc_decode_saving : ldpc_decode (same outputs, same arithmetic) that also keeps every
@@ -158,7 +158,8 @@ int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t ou
  *   codeword, tile-padded).
  * ldpc_backward      : grad_posterior[batch][n] fp32 (d loss / d posterior) and the
  *   iterations[batch] that decode returned -> grad_beta[T][n_beta_slots], grad_alpha[T][n_alpha_slots]
- *   fp32 (device, overwritten; either may be NULL).  The decoder's tables must be the ones the
+ *   fp32 and, for LDPC_C2V_OMS decoders created with oms_alpha, grad_oms_alpha[T][n_oms_alpha_slots]
+ *   (device, overwritten; any may be NULL).  The decoder's tables must be the ones the
  *   forward call used.  Slots autograd would leave without a gradient come back as 0.
  * Both need ldpc_train_workspace_bytes of 256-byte aligned scratch; `saved` is 256-byte aligned. */
 size_t ldpc_train_saved_bytes(const ldpc_decoder *d, int64_t batch);
@@ -169,8 +170,8 @@ int ldpc_decode_saving(const ldpc_decoder *d, const void *llr, int64_t batch, in
                        void *stream);
 int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, const void *llr,
                   int64_t batch, const int32_t *iterations, const void *grad_posterior,
-                  void *grad_beta, void *grad_alpha, void *workspace, size_t workspace_bytes,
-                  void *stream);
+                  void *grad_beta, void *grad_alpha, void *grad_oms_alpha, void *workspace,
+                  size_t workspace_bytes, void *stream);
 
 const char *ldpc_last_error(void);
 int ldpc_abi_version(void);

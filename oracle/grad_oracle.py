@@ -39,8 +39,12 @@ def _padded_neighbourhoods(g):
     return torch.from_numpy(ce), torch.from_numpy(ve)
 
 
-def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_stop=True, dtype=torch.float32):
+def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_stop=True, dtype=torch.float32,
+            offset=False):
     """llr [B, n]; beta_table [T, Sb], alpha_table [T, Sa] torch tensors (may require grad).
+    offset=False: normalised form, alpha_slot per VARIABLE (multiplies the leave-one-out sums).
+    offset=True : C2V = prod(signs) * (relu(minval - beta) - alpha), alpha_slot per EDGE, plain V2C sums
+                  (Neural2DOffsetMinSumDecoder, neural_2d_decoder.py:389-412; NeuralOffsetMinSumDecoder with alpha = 0).
     Returns (posterior [B, n] with grad_fn, bits int32 [B, n], iterations int64 [B])."""
     llr = torch.as_tensor(llr, dtype=dtype)
     B, n = llr.shape
@@ -50,7 +54,9 @@ def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_sto
     vmask = ve < E
     var_of_edge = torch.from_numpy(g.var_idx.astype(np.int64))
     bslot = torch.from_numpy(np.asarray(beta_slot, dtype=np.int64))
-    aslot_e = torch.from_numpy(np.asarray(alpha_slot, dtype=np.int64))[var_of_edge]       # alpha of the edge's variable
+    aslot_e = torch.from_numpy(np.asarray(alpha_slot, dtype=np.int64))
+    if not offset:
+        aslot_e = aslot_e[var_of_edge]                                                     # alpha of the edge's variable
     dc = torch.from_numpy(g.dc.astype(np.int64))
     chk_of_edge = torch.from_numpy(g.rows.astype(np.int64))
     pos_of_edge = torch.arange(E) - torch.from_numpy(g.check_ptr.astype(np.int64))[chk_of_edge]
@@ -83,8 +89,13 @@ def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_sto
         s_others = torch.where(eye_c.view(1, 1, max_dc, max_dc), torch.ones((), dtype=dtype), signs.unsqueeze(-2))
         prod_others = s_others.prod(dim=-1)                                        # [B, m, max_dc]
         beta_e = beta_table[t][bslot]                                              # [E]
-        c2v = (minval * prod_others)[:, chk_of_edge, pos_of_edge]                  # back to CSR edge order
-        c2v = beta_e.view(1, -1) * c2v
+        alpha_e = alpha_table[t][aslot_e]                                          # [E]
+        if offset:
+            raw = minval[:, chk_of_edge, pos_of_edge]                              # back to CSR edge order
+            c2v = prod_others[:, chk_of_edge, pos_of_edge] * (torch.relu(raw - beta_e.view(1, -1)) - alpha_e.view(1, -1))
+        else:
+            c2v = (minval * prod_others)[:, chk_of_edge, pos_of_edge]
+            c2v = beta_e.view(1, -1) * c2v
         c2v_pad = torch.cat([c2v, torch.zeros(B, 1, dtype=dtype)], dim=1)
         at_var = c2v_pad[:, ve]                                                    # [B, n, max_dv]
         post = llr + at_var.sum(dim=-1)                                            # no alpha (:206-209)
@@ -97,9 +108,8 @@ def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_sto
         done = done | newly
         # variable update (:203): leave-one-out sums
         others = torch.where(eye_v.view(1, 1, max_dv, max_dv), torch.zeros((), dtype=dtype), at_var.unsqueeze(-2)).sum(dim=-1)
-        alpha_e = alpha_table[t][aslot_e]                                          # [E]
         new_v2c = others[:, var_of_edge, kpos_of_edge]
-        v2c = llr[:, var_of_edge] + alpha_e.view(1, -1) * new_v2c
+        v2c = llr[:, var_of_edge] + (new_v2c if offset else alpha_e.view(1, -1) * new_v2c)
     final_post = torch.where(done.view(-1, 1), final_post, post)                   # not converged: last posterior
     return final_post, (final_post < 0).to(torch.int32), iters
 
@@ -114,11 +124,11 @@ def bce_loss_sum(posterior, targets=None):
 
 
 def table_grads(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_stop=True, targets=None,
-                dtype=torch.float32):
+                dtype=torch.float32, offset=False):
     """-> (grad beta [T, Sb], grad alpha [T, Sa], posterior, iterations) for bce_loss_sum"""
     bt = torch.tensor(np.asarray(beta_table), dtype=dtype, requires_grad=True)
     at = torch.tensor(np.asarray(alpha_table), dtype=dtype, requires_grad=True)
-    post, bits, iters = forward(g, llr, bt, beta_slot, at, alpha_slot, T, early_stop, dtype)
+    post, bits, iters = forward(g, llr, bt, beta_slot, at, alpha_slot, T, early_stop, dtype, offset)
     loss = bce_loss_sum(post, None if targets is None else torch.as_tensor(targets))
     gb, ga = torch.autograd.grad(loss, (bt, at), allow_unused=True)
     gb = torch.zeros_like(bt) if gb is None else gb

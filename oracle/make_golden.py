@@ -595,9 +595,9 @@ def _ref_grads(dec, llrs, targets=None):
     return gb, ga, np.stack(post), np.asarray(its, np.int32), np.asarray(losses, np.float64)
 
 
-def _check_grad_oracle(name, g, llrs, bt, bs, at, as_, T, gb_ref, ga_ref, post, its):
+def _check_grad_oracle(name, g, llrs, bt, bs, at, as_, T, gb_ref, ga_ref, post, its, offset=False):
     import grad_oracle
-    ogb, oga, opost, oit = grad_oracle.table_grads(g, llrs, bt, bs, at, as_, T)
+    ogb, oga, opost, oit = grad_oracle.table_grads(g, llrs, bt, bs, at, as_, T, offset=offset)
     check_equal(name + " iters", oit.astype(np.int32), its)
     if not np.allclose(opost, post, rtol=1e-5, atol=1e-5):
         raise SystemExit(f"GRAD ORACLE MISMATCH ({name}): posterior")
@@ -643,6 +643,44 @@ def run_grad_edge(code, H, llrs, T, seed):
                 beta_keys=bk, beta_vals=bv, grad_beta_table=gbt)
 
 
+def run_grad_offset2d(code, H, llrs, wtype, T, rng):
+    """Neural2DOffsetMinSumDecoder (relu(min - beta) - alpha, neural_2d_decoder.py:389-401) under autograd"""
+    g = oracle.OracleGraph(H)
+    dec = ref_n2d.Neural2DOffsetMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=T)
+    beta, alpha = set_weights(dec, rng, 0.0, 0.6, 0.0, 0.3)
+    gb, ga, post, its, losses = _ref_grads(dec, llrs)
+    bt, bs, at, as_ = oracle.weight_tables(g, wtype, T, beta, alpha, beta_default=0.0, alpha_default=0.0)
+    gbt, _, gat, _ = oracle.weight_tables(g, wtype, T, gb, ga, beta_default=0.0, alpha_default=0.0)
+    _check_grad_oracle(f"oms2d type {wtype}", g, llrs, bt, bs, at, as_[g.var_idx], T, gbt if gb else None,
+                       gat if ga else None, post, its, offset=True)
+    bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+    return dict(llr=llrs, posterior=post, iters=its, loss=losses, wtype=np.int32(wtype), T=np.int32(T),
+                beta_keys=bk, beta_vals=bv, alpha_keys=ak, alpha_vals=av,
+                grad_beta_keys=pack_weights(gb)[0], grad_beta_vals=np.asarray([gb[k] for k in sorted(gb)], np.float64),
+                grad_alpha_keys=pack_weights(ga)[0], grad_alpha_vals=np.asarray([ga[k] for k in sorted(ga)], np.float64),
+                grad_beta_table=gbt.astype(np.float64), grad_alpha_table=gat.astype(np.float64))
+
+
+def run_grad_edge_offset(code, H, llrs, T, seed):
+    """NeuralOffsetMinSumDecoder (relu(min - beta) per edge, neural_minsum_decoder.py:245-253) under autograd"""
+    g = oracle.OracleGraph(H)
+    torch.manual_seed(seed)
+    dec = ref_nms.NeuralOffsetMinSumDecoder(code, max_iterations=T)
+    with torch.no_grad():                                   # spread the offsets so relu() actually clips
+        for w in dec.beta_weights.values():
+            w.mul_(3.0).abs_()
+    beta = {k: float(v.detach().item()) for k, v in dec.beta_weights.items()}
+    gb, _, post, its, losses = _ref_grads(dec, llrs)
+    bt = oracle.edge_weight_table(g, T, beta)
+    gbt = oracle.edge_weight_table(g, T, gb).astype(np.float64)
+    zeros = np.zeros((max(T, 1), 1), np.float32)
+    _check_grad_oracle("edge offset", g, llrs, bt, np.arange(g.E, dtype=np.int32), zeros, np.zeros(g.E, np.int32), T,
+                       gbt, None, post, its, offset=True)
+    bk, bv = pack_weights(beta)
+    return dict(llr=llrs, posterior=post, iters=its, loss=losses, T=np.int32(T), seed=np.int32(seed),
+                beta_keys=bk, beta_vals=bv, grad_beta_table=gbt)
+
+
 def gen_grad(which):
     rng = np.random.default_rng(8642)
     if which == "toy":
@@ -657,6 +695,11 @@ def gen_grad(which):
                     out[f"t{wtype}_T{T}_{k}"] = v
         for k, v in run_grad_edge(code, H, llrs, 4, seed=77).items():
             out[f"edge_{k}"] = v
+        for wtype in (1, 2, 3, 4):
+            for k, v in run_grad_offset2d(code, H, llrs, wtype, 4, rng).items():
+                out[f"o{wtype}_T4_{k}"] = v
+        for k, v in run_grad_edge_offset(code, H, llrs, 4, seed=78).items():
+            out[f"edgeoff_{k}"] = v
     else:
         H = load_edge_list("small_96_48")
         code = CachedCode(n=96, k=48, H=H, max_iterations=10)
@@ -666,6 +709,8 @@ def gen_grad(which):
         for wtype, T in ((2, 4), (1, 3)):
             for k, v in run_grad_neural2d(code, H, llrs, wtype, T, rng).items():
                 out[f"t{wtype}_T{T}_{k}"] = v
+        for k, v in run_grad_offset2d(code, H, llrs, 2, 4, rng).items():
+            out[f"o2_T4_{k}"] = v
     return out
 
 

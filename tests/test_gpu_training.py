@@ -42,10 +42,10 @@ def assert_grads(got, want, what, rtol=1e-4, atol=2e-6):
         assert abs(got[k] - want[k]) <= atol + rtol * abs(want[k]), f"{what} {k}: {got[k]} vs reference {want[k]}"
 
 
-def check_neural2d_block(gold, sub, gpu, batched=True):
-    from neural_2d_decoder import Neural2DMinSumDecoder
+def check_neural2d_block(gold, sub, gpu, batched=True, offset=False):
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
     T, wtype = int(sub["T"]), int(sub["wtype"])
-    dec = Neural2DMinSumDecoder(make_code(gold, T), wtype, T)
+    dec = (Neural2DOffsetMinSumDecoder if offset else Neural2DMinSumDecoder)(make_code(gold, T), wtype, T)
     beta = weights_dict(sub["beta_keys"], sub["beta_vals"])
     alpha = weights_dict(sub["alpha_keys"], sub["alpha_vals"])
     sd = {f"beta_weights.{k}": torch.tensor([v]) for k, v in beta.items()}
@@ -89,6 +89,31 @@ def test_golden_toy_single_vector_calls_accumulate(gpu_device):
 def test_golden_small_neural2d_gradients(gpu_device, tag):
     gold = load_golden("grad_small")
     check_neural2d_block(gold, golden_sub(gold, tag), gpu_device)
+
+
+@pytest.mark.parametrize("name,tag", [("grad_toy", "o1_T4"), ("grad_toy", "o2_T4"), ("grad_toy", "o3_T4"),
+                                      ("grad_toy", "o4_T4"), ("grad_small", "o2_T4")])
+def test_golden_offset_form_gradients(gpu_device, name, tag):
+    """Neural2DOffsetMinSumDecoder: relu(min - beta) - alpha, both trainable"""
+    gold = load_golden(name)
+    check_neural2d_block(gold, golden_sub(gold, tag), gpu_device, offset=True)
+
+
+def test_golden_toy_edge_offset_gradients(gpu_device):
+    from neural_minsum_decoder import NeuralOffsetMinSumDecoder
+    import oracle
+    gold = load_golden("grad_toy")
+    sub = golden_sub(gold, "edgeoff")
+    T = int(sub["T"])
+    dec = NeuralOffsetMinSumDecoder(make_code(gold, T), T)
+    dec.load_state_dict({f"beta_weights.{k}": torch.tensor([v])
+                         for k, v in weights_dict(sub["beta_keys"], sub["beta_vals"]).items()})
+    bits, post, iters = dec(torch.from_numpy(sub["llr"]).to(gpu_device))
+    np.testing.assert_array_equal(iters.cpu().numpy(), sub["iters"])
+    np.testing.assert_allclose(post.detach().cpu().numpy(), sub["posterior"], rtol=1e-5, atol=1e-5)
+    codeword_loss_sum(post).backward()
+    got = oracle.edge_weight_table(oracle.OracleGraph(gold["H"]), T, param_grads(dec.beta_weights))
+    np.testing.assert_allclose(got, sub["grad_beta_table"], rtol=1e-4, atol=2e-6)
 
 
 def test_golden_toy_edge_weight_gradients(gpu_device):
@@ -139,7 +164,7 @@ def test_engine_backward_vs_oracle_on_the_1998_code(gpu_device, early_stop, batc
     if early_stop:
         assert len(torch.unique(res.iterations)) >= 2
     gpost = rng.standard_normal((batch, n)).astype(np.float32)
-    gb, ga = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost).to(gpu_device))
+    gb, ga, _ = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost).to(gpu_device))
 
     g = oracle.OracleGraph(n=n, check_ptr=code.tanner_graph().check_ptr, var_idx=code.tanner_graph().var_idx)
     bt_np, at_np = dec.weight_tables()
@@ -152,7 +177,7 @@ def test_engine_backward_vs_oracle_on_the_1998_code(gpu_device, early_stop, batc
     assert agree.mean() > 0.98        # a different summation order may flip a near-tie; those codewords are left out
     gpost_m = gpost * agree[:, None]
     (post * torch.from_numpy(gpost_m)).sum().backward()
-    gb2, ga2 = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost_m).to(gpu_device))
+    gb2, ga2, _ = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost_m).to(gpu_device))
     for got, want, what in ((gb2, bt.grad, "beta"), (ga2, at.grad, "alpha")):
         got, want = got.cpu().numpy(), want.numpy()
         scale = np.abs(want).max()

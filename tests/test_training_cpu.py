@@ -40,6 +40,34 @@ def test_gradient_oracle_equals_reference_autograd(name, tags, oracle_mod):
             np.testing.assert_allclose(ga, sub["grad_alpha_table"], rtol=2e-4, atol=2e-6, err_msg=tag)
 
 
+@pytest.mark.parametrize("name,tags", [("grad_toy", ["o1_T4", "o2_T4", "o3_T4", "o4_T4"]), ("grad_small", ["o2_T4"])])
+def test_gradient_oracle_offset_form_equals_reference_autograd(name, tags, oracle_mod):
+    import grad_oracle
+    gold = load_golden(name)
+    g = _graph(gold, oracle_mod)
+    for tag in tags:
+        sub = golden_sub(gold, tag)
+        T, wtype = int(sub["T"]), int(sub["wtype"])
+        bt, bs, at, as_ = oracle_mod.weight_tables(g, wtype, T, weights_dict(sub["beta_keys"], sub["beta_vals"]),
+                                                   weights_dict(sub["alpha_keys"], sub["alpha_vals"]),
+                                                   beta_default=0.0, alpha_default=0.0)
+        gb, ga, post, iters = grad_oracle.table_grads(g, sub["llr"], bt, bs, at, as_[g.var_idx], T, offset=True)
+        np.testing.assert_array_equal(iters, sub["iters"])
+        np.testing.assert_allclose(post, sub["posterior"], rtol=1e-5, atol=1e-5)
+        if len(sub["grad_beta_keys"]):
+            np.testing.assert_allclose(gb, sub["grad_beta_table"], rtol=2e-4, atol=2e-6, err_msg=tag)
+        if len(sub["grad_alpha_keys"]):
+            np.testing.assert_allclose(ga, sub["grad_alpha_table"], rtol=2e-4, atol=2e-6, err_msg=tag)
+    if name == "grad_toy":
+        sub = golden_sub(gold, "edgeoff")
+        T = int(sub["T"])
+        bt = oracle_mod.edge_weight_table(g, T, weights_dict(sub["beta_keys"], sub["beta_vals"]))
+        gb, _, _, iters = grad_oracle.table_grads(g, sub["llr"], bt, np.arange(g.E), np.zeros((T, 1), np.float32),
+                                                  np.zeros(g.E, np.int64), T, offset=True)
+        np.testing.assert_array_equal(iters, sub["iters"])
+        np.testing.assert_allclose(gb, sub["grad_beta_table"], rtol=2e-4, atol=2e-6)
+
+
 def test_gradient_oracle_edge_weights_equal_reference_autograd(oracle_mod):
     import grad_oracle
     gold = load_golden("grad_toy")
