@@ -90,3 +90,32 @@ def decode_sharded(engine, llr_local: torch.Tensor, total: int, *, early_stop: b
     res = engine.decode(llr_local, early_stop=early_stop, want_bits=False, want_posterior=False,
                         want_packed=True)
     return all_gather_hard_decisions(res.packed_bits, total, group), res
+
+
+def all_reduce_gradients(parameters, group: Optional[dist.ProcessGroup] = None, average: bool = True) -> int:
+    """Data-parallel training: sum (or average) the `.grad` of every parameter over the ranks with ONE
+    all-reduce of a flat buffer (the decoders have a few hundred scalar weights; one bucket, not one collective
+    per [1]-shaped parameter).  Parameters without a gradient on this rank contribute zeros, so every rank ends
+    with the same gradients.  Returns the number of scalars reduced.  RCCL with backend "nccl" when the
+    parameters live on the GPU, gloo on the CPU."""
+    params = [p for p in parameters if p.requires_grad]
+    if not params:
+        return 0
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sum(p.numel() for p in params)
+    dev, dt = params[0].device, params[0].dtype
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(device=dev, dtype=dt)
+                      for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        k = p.numel()
+        g = flat[off:off + k].reshape(p.shape).to(device=p.device, dtype=p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += k
+    return off

@@ -54,6 +54,7 @@ class TrainingConfig:
     clip_threshold: float = 1e-3
     device: str = "cuda"
     llr_convention: str = "decoder"          # "reference": simulate_awgn_channel literally (see module docstring)
+    data_parallel: bool = False              # one process per GPU: average the gradients over the ranks every step
     seed: Optional[int] = None               # training-data noise seed (decoder convention only)
 
 
@@ -113,6 +114,9 @@ class PosteriorJointTrainer:
             decoded, posteriors, iterations = self.model(llrs)
             loss = self.compute_loss(decoded, targets, posteriors)
             loss.backward()
+            if self.config.data_parallel:              # each rank trained on its own shard of the batch
+                import sharding
+                sharding.all_reduce_gradients(self.model.parameters())
             total_norm = _grad_norm(self.model)
             epoch_grad_norms.append(total_norm)
             if self.config.use_gradient_clipping:

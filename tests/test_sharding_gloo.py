@@ -90,3 +90,48 @@ def test_pack_unpack_roundtrip_and_format():
     assert sharding.pack_bits(one).tolist() == [[0, 4, 0]]
     # single process: the "gather" is the identity
     assert sharding.all_gather_hard_decisions(packed, 33) is packed
+
+
+def _grad_worker(rank, world, port, q):
+    from conftest import PKG  # noqa: F401
+    import sharding
+    from ldpc_decoder import create_test_ldpc_code
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = Neural2DMinSumDecoder(create_test_ldpc_code(), 2, 3)      # same init on every rank
+        names = [k for k, _ in model.named_parameters()]
+        for i, (k, p) in enumerate(model.named_parameters()):            # rank-dependent fake gradients, one left at None
+            if not (rank == 1 and i == 2):
+                p.grad = torch.full_like(p, float((rank + 1) * (i + 1)))
+        count = sharding.all_reduce_gradients(model.parameters())
+        want = []
+        for i in range(len(names)):
+            tot = sum(0.0 if (r == 1 and i == 2) else float((r + 1) * (i + 1)) for r in range(world))
+            want.append(tot / world)
+        got = [float(p.grad.item()) for p in model.parameters()]
+        q.put((rank, count == len(names), got, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_all_reduce():
+    """one bucketed all-reduce averages the table gradients over the ranks (gloo here, RCCL on the GPUs)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, got, want in res:
+        assert ok
+        assert got == pytest.approx(want)
+    assert res[0][2] == res[1][2]
