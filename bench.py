@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--sweep-reps", type=int, default=20)
     ap.add_argument("--no-overlap", action="store_true", help="join every step's all-gather before the next decode")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch (default: the workload's) is the TOTAL over all GPUs, split evenly")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +170,10 @@ def main():
 
     gname, T, default_batch, desc = WORKLOADS[args.workload]
     B = args.batch or default_batch
+    if args.strong:                                              # fixed total work, B / world per GPU
+        if B % world:
+            raise SystemExit(f"--strong: total batch {B} is not divisible by {world} GPUs")
+        B //= world
     eng, dec, code = build_decoder(args.workload, device)
     g = code.tanner_graph()
     llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device)
@@ -228,7 +234,7 @@ def main():
     out = {
         "metric": "decoded codewords/sec at fixed iters; achieved HBM GB/s vs peak",
         "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{desc}, {T} iterations, batch {B}/GPU, SNR {args.snr_db} dB, "
                                f"{'early-stop' if early else 'fixed-iteration'} flooding decode",

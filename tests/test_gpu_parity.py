@@ -578,3 +578,33 @@ def test_packed_bits_and_threads(gpu_device):
         outs = list(ex.map(work, range(4)))
     for o in outs:
         np.testing.assert_array_equal(o, ref_bits.detach().cpu().numpy())
+
+
+def test_decode_is_capturable_in_a_hip_graph(gpu_device, engine_mode):
+    """ldpc_decode only enqueues work on the caller's stream (no allocation, no synchronisation), so a launch-bound
+    caller can capture it once and replay it: replays on new inputs equal eager decodes"""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    code = codes.load_code("small_96_48", max_iterations=6)
+    eng = BasicMinSumDecoder(code, 0.7)._engine(torch.float32, gpu_device)
+    gen = torch.Generator(device=gpu_device).manual_seed(77)
+    x_static = torch.randn(200, code.n, device=gpu_device, generator=gen) * 2 + 1.5
+    eng.decode(x_static)                                   # warm-up: workspace allocation, kernel attributes
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(side):
+        eng.decode(x_static)
+    torch.cuda.current_stream(gpu_device).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res = eng.decode(x_static, early_stop=True)
+    for trial in range(3):
+        x_new = torch.randn(200, code.n, device=gpu_device, generator=gen) * 2 + 1.0 + 0.3 * trial
+        x_static.copy_(x_new)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (res.bits.clone(), res.posterior.clone(), res.iterations.clone(), res.success.clone())
+        ref = eng.decode(x_new, early_stop=True)
+        assert torch.equal(got[0], ref.bits) and torch.equal(got[1], ref.posterior)
+        assert torch.equal(got[2], ref.iterations)
