@@ -441,6 +441,58 @@ __device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentA
     }
 }
 
+// res_emit for every codeword of `open` at once (end of a fixed-T decode): the inverse-permutation entries of a
+// batch are loaded first, one ds_read of the codeword pair per position, then the coalesced row stores
+template <int G>
+__device__ __forceinline__ void res_emit_open(const ResidentPlan &pl, const ResidentArgs &a, const float *__restrict__ llr_s,
+                                              long long b0, unsigned open, int iters, unsigned unsat, int tid, int nt)
+{
+    using P = Pack<float, G>;
+    const int n = pl.n;
+    constexpr int kB = 4;
+    if (a.posterior || a.bits) {
+        for (int j0 = tid; j0 < n; j0 += kB * nt) {
+            unsigned ip[kB];
+#pragma unroll
+            for (int k = 0; k < kB; ++k) ip[k] = (j0 + k * nt < n) ? pl.inv_perm_v[j0 + k * nt] : 0u;
+#pragma unroll
+            for (int k = 0; k < kB; ++k) {
+                const int j = j0 + k * nt;
+                if (j < n) {
+                    const P p = reinterpret_cast<const P *>(llr_s)[ip[k]];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if ((open >> g) & 1u) {
+                            if (a.posterior) a.posterior[(size_t)(b0 + g) * n + j] = p.x[g];
+                            if (a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < 0.0f ? 1 : 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!((open >> g) & 1u)) continue;
+        if (a.packed) {
+            const int nbytes = (n + 7) / 8;
+            for (int k = tid; k < nbytes; k += nt) {
+                unsigned v = 0;
+#pragma unroll
+                for (int qb = 0; qb < 8; ++qb) {
+                    const int j = k * 8 + qb;
+                    if (j < n && llr_s[(int)pl.inv_perm_v[j] * G + g] < 0.0f) v |= 1u << qb;
+                }
+                a.packed[(size_t)(b0 + g) * nbytes + k] = (uint8_t)v;
+            }
+        }
+        if (tid == 0) {
+            if (a.iterations) a.iterations[b0 + g] = iters;
+            if (a.success) a.success[b0 + g] = (uint8_t)(((unsat >> g) & 1u) ? 0 : 1);
+        }
+    }
+}
+
 // outputs of codeword g when no posterior was asked for: hard decisions straight from bits_s (sorted order)
 template <int G>
 __device__ __forceinline__ void res_emit_bits(const ResidentPlan &pl, const ResidentArgs &a, const uint8_t *__restrict__ bits_s,
@@ -493,13 +545,29 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     constexpr unsigned kAll = (1u << G) - 1u;
     if (LDPC_PROBE(a, 64)) return;                       // launch-overhead probe
 
-    // LLRs: coalesced rows from HBM, scattered into degree-sorted order; padding codewords get +1
+    // LLRs: coalesced rows from HBM, scattered into degree-sorted order; padding codewords get +1.
+    // All loads of a batch of kPro positions are issued before the first LDS store: one HBM round trip per
+    // batch instead of one per element (the plain loop waits for every load before it issues the next).
+    constexpr int kPro = 4;
+    if (!LDPC_PROBE(a, 16)) {
+        for (int j0 = tid; j0 < n; j0 += kPro * nt) {
+            unsigned ip[kPro];
+            P v[kPro];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const bool live = b0 + g < a.batch;
-        const float *row = a.llr + (size_t)(b0 + g) * n;
-        if (!LDPC_PROBE(a, 16))
-            for (int j = tid; j < n; j += nt) llr_s[(int)pl.inv_perm_v[j] * G + g] = live ? row[j] : 1.0f;
+            for (int k = 0; k < kPro; ++k) {
+                const int j = j0 + k * nt;
+                ip[k] = 0;
+                if (j < n) {
+                    ip[k] = pl.inv_perm_v[j];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        v[k].x[g] = (b0 + g < a.batch) ? a.llr[(size_t)(b0 + g) * n + j] : 1.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPro; ++k)
+                if (j0 + k * nt < n) reinterpret_cast<P *>(llr_s)[ip[k]] = v[k];
+        }
     }
     for (int k = tid; k < n_alpha_lds; k += nt) alpha_s[k] = a.alpha[k];
     if (tid == 0) *sh_unsat = 0;
@@ -507,19 +575,36 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
         const P *L = reinterpret_cast<const P *>(llr_s);
-        for (int q = tid; q < n && !LDPC_PROBE(a, 32); q += nt) {
-            const int dv = (int)(pl.vmeta[q] & 0xffu);
-            const uint4 slo = pl.vslot_lo[q];
-            const uint4 shi = pl.max_dv > 4 ? pl.vslot_hi[q] : make_uint4(0, 0, 0, 0);
-            const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
-            P l = L[q];
-            if (a.T == 0) {
+        for (int q0 = tid; q0 < n && !LDPC_PROBE(a, 32); q0 += kPro * nt) {
+            int dvk[kPro];
+            uint4 slo[kPro], shi[kPro];
 #pragma unroll
-                for (int g = 0; g < G; ++g) l.x[g] = 0.0f;
+            for (int k = 0; k < kPro; ++k) {                       // plan loads of the whole batch first
+                const int q = q0 + k * nt;
+                dvk[k] = 0;
+                slo[k] = make_uint4(0, 0, 0, 0);
+                shi[k] = make_uint4(0, 0, 0, 0);
+                if (q < n) {
+                    dvk[k] = (int)(pl.vmeta[q] & 0xffu);
+                    slo[k] = pl.vslot_lo[q];
+                    if (pl.max_dv > 4) shi[k] = pl.vslot_hi[q];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < dv) lds_store<P>(off[k], l);
+            for (int k = 0; k < kPro; ++k) {
+                const int q = q0 + k * nt;
+                if (q < n) {
+                    const unsigned off[8] = {slo[k].x, slo[k].y, slo[k].z, slo[k].w, shi[k].x, shi[k].y, shi[k].z, shi[k].w};
+                    P l = L[q];
+                    if (a.T == 0) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) l.x[g] = 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < dvk[k]) lds_store<P>(off[e], l);
+                }
+            }
         }
     }
     // first-round check degree (iteration-invariant) and per-check beta of iteration 0, in registers
@@ -613,9 +698,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         unsat = *sh_unsat;
     }
     if (LDPC_PROBE(a, 4)) return;
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-        if ((open >> g) & 1u) res_emit<G>(pl, a, llr_s, b0 + g, g, a.T, ((unsat >> g) & 1u) ? 0 : 1, tid, nt);
+    res_emit_open<G>(pl, a, llr_s, b0, open, a.T, unsat, tid, nt);
 }
 
 }  // namespace ldpc
