@@ -410,113 +410,94 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
     if (acc) atomicOr(sh_unsat, acc);
 }
 
-// write codeword g's outputs; its posterior sits in llr_s[.][g] (sorted order)
+// ---- outputs ---------------------------------------------------------------------------------------------
+// Positions are walked in ORIGINAL variable order j = tid + k*nt (coalesced row stores); the inverse-permutation
+// entries of a batch of kEmit positions are loaded before the first LDS read (one round trip per batch), and the
+// bit-packed row (the multi-GPU wire format) falls out of a wave ballot over 64 consecutive positions: lanes 0..7
+// store the 8 bytes.  `mask`: codewords of the workgroup to write.
+constexpr int kEmit = 4;
+
 template <int G>
-__device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentArgs &a, const float *__restrict__ llr_s,
-                                         long long b, int g, int iters, int success, int tid, int nt)
+__device__ __forceinline__ void res_store_packed(const ResidentArgs &a, long long b, int j, int n, bool neg)
 {
-    const int n = pl.n;
-    if (a.posterior || a.bits) {
-        for (int j = tid; j < n; j += nt) {
-            const float p = llr_s[(int)pl.inv_perm_v[j] * G + g];
-            if (a.posterior) a.posterior[(size_t)b * n + j] = p;
-            if (a.bits) a.bits[(size_t)b * n + j] = p < 0.0f ? 1 : 0;
-        }
-    }
-    if (a.packed) {
-        const int nbytes = (n + 7) / 8;
-        for (int k = tid; k < nbytes; k += nt) {
-            unsigned v = 0;
-#pragma unroll
-            for (int qb = 0; qb < 8; ++qb) {
-                const int j = k * 8 + qb;
-                if (j < n && llr_s[(int)pl.inv_perm_v[j] * G + g] < 0.0f) v |= 1u << qb;
-            }
-            a.packed[(size_t)b * nbytes + k] = (uint8_t)v;
-        }
-    }
-    if (tid == 0) {
-        if (a.iterations) a.iterations[b] = iters;
-        if (a.success) a.success[b] = (uint8_t)success;
-    }
+    const unsigned long long m = __ballot(neg);
+    const int lane = threadIdx.x & 63;
+    const int base = j - lane;                       // first position of this wave's 64
+    if (lane < 8 && base + 8 * lane < n) a.packed[(size_t)b * ((n + 7) / 8) + (base >> 3) + lane] = (uint8_t)(m >> (8 * lane));
 }
 
-// res_emit for every codeword of `open` at once (end of a fixed-T decode): the inverse-permutation entries of a
-// batch are loaded first, one ds_read of the codeword pair per position, then the coalesced row stores
+// posterior of the masked codewords sits in llr_s[.][g] (sorted order)
 template <int G>
-__device__ __forceinline__ void res_emit_open(const ResidentPlan &pl, const ResidentArgs &a, const float *__restrict__ llr_s,
-                                              long long b0, unsigned open, int iters, unsigned unsat, int tid, int nt)
+__device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentArgs &a, const float *__restrict__ llr_s,
+                                         long long b0, unsigned mask, int iters, unsigned unsat, int tid, int nt)
 {
     using P = Pack<float, G>;
     const int n = pl.n;
-    constexpr int kB = 4;
-    if (a.posterior || a.bits) {
-        for (int j0 = tid; j0 < n; j0 += kB * nt) {
-            unsigned ip[kB];
+    if (a.posterior || a.bits || a.packed) {
+        for (int j0 = tid; j0 < n; j0 += kEmit * nt) {
+            unsigned ip[kEmit];
 #pragma unroll
-            for (int k = 0; k < kB; ++k) ip[k] = (j0 + k * nt < n) ? pl.inv_perm_v[j0 + k * nt] : 0u;
+            for (int k = 0; k < kEmit; ++k) ip[k] = (j0 + k * nt < n) ? pl.inv_perm_v[j0 + k * nt] : 0u;
 #pragma unroll
-            for (int k = 0; k < kB; ++k) {
+            for (int k = 0; k < kEmit; ++k) {
                 const int j = j0 + k * nt;
-                if (j < n) {
-                    const P p = reinterpret_cast<const P *>(llr_s)[ip[k]];
+                if (j - (tid & 63) >= n) break;                       // the whole wave is past the row (wave-uniform)
+                const bool in = j < n;
+                const P p = reinterpret_cast<const P *>(llr_s)[ip[k]];  // ip = 0 for lanes past the row: harmless read
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if ((open >> g) & 1u) {
-                            if (a.posterior) a.posterior[(size_t)(b0 + g) * n + j] = p.x[g];
-                            if (a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < 0.0f ? 1 : 0;
-                        }
-                    }
+                for (int g = 0; g < G; ++g) {
+                    if (!((mask >> g) & 1u)) continue;
+                    if (in && a.posterior) a.posterior[(size_t)(b0 + g) * n + j] = p.x[g];
+                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < 0.0f ? 1 : 0;
+                    if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && p.x[g] < 0.0f);
                 }
             }
         }
     }
+    if (tid == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (!((open >> g) & 1u)) continue;
-        if (a.packed) {
-            const int nbytes = (n + 7) / 8;
-            for (int k = tid; k < nbytes; k += nt) {
-                unsigned v = 0;
-#pragma unroll
-                for (int qb = 0; qb < 8; ++qb) {
-                    const int j = k * 8 + qb;
-                    if (j < n && llr_s[(int)pl.inv_perm_v[j] * G + g] < 0.0f) v |= 1u << qb;
-                }
-                a.packed[(size_t)(b0 + g) * nbytes + k] = (uint8_t)v;
-            }
-        }
-        if (tid == 0) {
+        for (int g = 0; g < G; ++g) {
+            if (!((mask >> g) & 1u)) continue;
             if (a.iterations) a.iterations[b0 + g] = iters;
             if (a.success) a.success[b0 + g] = (uint8_t)(((unsat >> g) & 1u) ? 0 : 1);
         }
     }
 }
 
-// outputs of codeword g when no posterior was asked for: hard decisions straight from bits_s (sorted order)
+// outputs when no posterior was asked for: hard decisions straight from bits_s (sorted order, bit g = codeword g)
 template <int G>
 __device__ __forceinline__ void res_emit_bits(const ResidentPlan &pl, const ResidentArgs &a, const uint8_t *__restrict__ bits_s,
-                                              long long b, int g, int iters, int success, int tid, int nt)
+                                              long long b0, unsigned mask, int iters, unsigned unsat, int tid, int nt)
 {
     const int n = pl.n;
-    if (a.bits) {
-        for (int j = tid; j < n; j += nt) a.bits[(size_t)b * n + j] = (bits_s[pl.inv_perm_v[j]] >> g) & 1;
-    }
-    if (a.packed) {
-        const int nbytes = (n + 7) / 8;
-        for (int k = tid; k < nbytes; k += nt) {
-            unsigned v = 0;
+    if (a.bits || a.packed) {
+        for (int j0 = tid; j0 < n; j0 += kEmit * nt) {
+            unsigned ip[kEmit];
 #pragma unroll
-            for (int qb = 0; qb < 8; ++qb) {
-                const int j = k * 8 + qb;
-                if (j < n) v |= (unsigned)((bits_s[pl.inv_perm_v[j]] >> g) & 1) << qb;
+            for (int k = 0; k < kEmit; ++k) ip[k] = (j0 + k * nt < n) ? pl.inv_perm_v[j0 + k * nt] : 0u;
+#pragma unroll
+            for (int k = 0; k < kEmit; ++k) {
+                const int j = j0 + k * nt;
+                if (j - (tid & 63) >= n) break;
+                const bool in = j < n;
+                const unsigned bb = bits_s[ip[k]];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (!((mask >> g) & 1u)) continue;
+                    const unsigned bit = (bb >> g) & 1u;
+                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = (int)bit;
+                    if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && bit != 0);
+                }
             }
-            a.packed[(size_t)b * nbytes + k] = (uint8_t)v;
         }
     }
     if (tid == 0) {
-        if (a.iterations) a.iterations[b] = iters;
-        if (a.success) a.success[b] = (uint8_t)success;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (!((mask >> g) & 1u)) continue;
+            if (a.iterations) a.iterations[b0 + g] = iters;
+            if (a.success) a.success[b0 + g] = (uint8_t)(((unsat >> g) & 1u) ? 0 : 1);
+        }
     }
 }
 
@@ -644,9 +625,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             if (tid == 0) *sh_unsat = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-                    if ((newly >> g) & 1u) res_emit_bits<G>(pl, a, bits_s, b0 + g, g, it + 1, 1, tid, nt);
+                res_emit_bits<G>(pl, a, bits_s, b0, newly, it + 1, 0u, tid, nt);
                 done |= newly;
                 if (done == kAll) return;
                 __syncthreads();                         // bits_s is rewritten by the next iteration
@@ -665,9 +644,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             if (newly) {                                 // block-uniform
                 res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, newly, tid, nt);
                 __syncthreads();
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-                    if ((newly >> g) & 1u) res_emit<G>(pl, a, llr_s, b0 + g, g, it + 1, 1, tid, nt);
+                res_emit<G>(pl, a, llr_s, b0, newly, it + 1, 0u, tid, nt);
                 done |= newly;
                 if (done == kAll) return;                // every codeword of the block has its outputs
                 __syncthreads();
@@ -684,9 +661,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     const unsigned open = ~done & kAll;
     if (!open) return;
     if (ES && !a.posterior && a.T > 0) {                 // bits_s hold iteration T's decisions already
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if ((open >> g) & 1u) res_emit_bits<G>(pl, a, bits_s, b0 + g, g, a.T, 0, tid, nt);
+        res_emit_bits<G>(pl, a, bits_s, b0, open, a.T, kAll, tid, nt);
         return;
     }
     if (!LDPC_PROBE(a, 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
@@ -698,7 +673,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         unsat = *sh_unsat;
     }
     if (LDPC_PROBE(a, 4)) return;
-    res_emit_open<G>(pl, a, llr_s, b0, open, a.T, unsat, tid, nt);
+    res_emit<G>(pl, a, llr_s, b0, open, a.T, unsat, tid, nt);
 }
 
 }  // namespace ldpc

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--workload", default="basic")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--packed", action="store_true", help="also ask for the bit-packed hard decisions (multi-GPU wire format)")
     ap.add_argument("--tag", default=os.environ.get("LDPC_HIP_LIB", "default"))
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -31,13 +32,13 @@ def main():
         eng, dec, code = bench.build_decoder(a.workload, dev)
     llr = bench.make_llr(B, code.n, 2.0, 1234, dev)
     for _ in range(2):
-        eng.decode(llr, early_stop=False, want_posterior=False)
+        eng.decode(llr, early_stop=False, want_posterior=False, want_packed=a.packed)
     torch.cuda.synchronize()
     ev = lambda: torch.cuda.Event(enable_timing=True)
     e0, e1 = ev(), ev()
     e0.record()
     for _ in range(5):
-        eng.decode(llr, early_stop=False, want_posterior=False)
+        eng.decode(llr, early_stop=False, want_posterior=False, want_packed=a.packed)
     e1.record(); e1.synchronize()
     out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5,
            "engine": eng.info()}
