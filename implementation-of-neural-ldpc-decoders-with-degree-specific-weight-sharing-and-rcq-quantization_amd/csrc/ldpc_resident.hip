@@ -325,7 +325,15 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
             byte |= (post < 0.0f ? 1u : 0u) << g;
             if ((emask >> g) & 1u) { l.x[g] = post; store = true; }
         }
-        bits_s[q] = (uint8_t)byte;
+        if constexpr (MODE == 8) {
+            // last pass of a fixed-T decode: the c2v values in this variable's slots are dead once read above, so the
+            // hard decisions go there (bit g = codeword g) and the final syndrome reads them back with consecutive
+            // addresses per check (res_syndrome_slots) instead of gathering bytes through global index loads
+#pragma unroll
+            for (int k = 0; k < DV; ++k) lds_store<unsigned>(off[k], byte);
+        } else {
+            bits_s[q] = (uint8_t)byte;
+        }
         if (store) L[q] = l;
     }
 }
@@ -404,6 +412,27 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
             for (int t = 0; t < dcw; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
         } else {
             for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
+        }
+        acc |= x;
+    }
+    if (acc) atomicOr(sh_unsat, acc);
+}
+
+// final syndrome of a fixed-T decode from the hard decisions res_var_body<MODE 8> left in the message slots
+template <int G>
+__device__ __forceinline__ void res_syndrome_slots(const ResidentPlan &pl, unsigned *sh_unsat, int tid, int nt)
+{
+    constexpr unsigned kSlot = sizeof(Pack<float, G>);
+    unsigned acc = 0;
+    for (int p = tid; p < pl.m; p += nt) {
+        const int dc = pl.dc_s[p];
+        int dcw;
+        unsigned x = 0;
+        if (wave_uniform(dc, dcw)) {
+#pragma unroll 8
+            for (int t = 0; t < dcw; ++t) x ^= lds_load<unsigned>((unsigned)(t * pl.mstride + p) * kSlot);
+        } else {
+            for (int t = 0; t < dc; ++t) x ^= lds_load<unsigned>((unsigned)(t * pl.mstride + p) * kSlot);
         }
         acc |= x;
     }
@@ -664,11 +693,14 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         res_emit_bits<G>(pl, a, bits_s, b0, open, a.T, kAll, tid, nt);
         return;
     }
-    if (!LDPC_PROBE(a, 8)) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
+    if (!LDPC_PROBE(a, 8)) {
+        if (ES) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
+        else res_var_phase<G, 8>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
+    }
     __syncthreads();
     unsigned unsat = kAll;
     if (!ES && !LDPC_PROBE(a, 8)) {                    // fixed-T mode: success = final syndrome is zero
-        res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
+        res_syndrome_slots<G>(pl, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
     }
