@@ -198,7 +198,9 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t sel = (__builtin_fabsf(v.x[g]) == m1[g]) ? o2[g] : o1[g];
-                o.x[g] = __uint_as_float(sel ^ (__float_as_uint(v.x[g]) & 0x80000000u));
+                // sel ^ (x & sign bit) as ONE v_bitop3_b32 (truth table a ^ (b & c) = 0x78); written with & and ^ the
+                // compiler emits v_and + v_xor here
+                o.x[g] = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(v.x[g]), 0x80000000u, 0x78));
             }
             lds_store<P>(addr, o);
         }
