@@ -93,6 +93,7 @@ struct ldpc_decoder {
     bool res_ok = false;
     int res_G = 0, res_NT = 0;
     bool unit_alpha = false, rcq_zero0 = false;   // table properties the resident kernel exploits
+    bool beta_per_check = false;                  // every edge of a check uses the same beta slot
     size_t res_lds = 0;
     ResidentPlan res{};
     std::vector<void *> res_bufs;  // device allocations owned by the plan
@@ -171,12 +172,12 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     } else {
         if constexpr (sizeof(T) == 4) {
             if (d->n_levels == 4) {                      // bc = 3: compare chain with a compile-time length
-                if (first)
-                    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, true, 4>), grid, block, 0, s, g, src, (void *)w.c2v,
-                                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb);
-                else
-                    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, false, 4>), grid, block, 0, s, g, src, (void *)w.c2v,
-                                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb);
+#define LDPC_CN_RCQ4(FIRST_, BPC_)                                                                                  \
+    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, FIRST_, 4, BPC_>), grid, block, 0, s, g, src, (void *)w.c2v,       \
+                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb)
+                if (d->beta_per_check) { if (first) LDPC_CN_RCQ4(true, true); else LDPC_CN_RCQ4(false, true); }
+                else { if (first) LDPC_CN_RCQ4(true, false); else LDPC_CN_RCQ4(false, false); }
+#undef LDPC_CN_RCQ4
             } else {
                 if (first) LDPC_CN(FORM_RCQ, true); else LDPC_CN(FORM_RCQ, false);
             }
@@ -756,6 +757,10 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
         if (!rc) rc = up_bytes(&d->alpha, nullptr, (size_t)d->n_alpha * es);
     }
     if (!rc) rc = upload(&d->beta_slot, desc->beta_slot, (size_t)g->E);
+    d->beta_per_check = true;
+    for (int i = 0; i < g->m && d->beta_per_check; ++i)
+        for (int e = g->h_check_ptr[i] + 1; e < g->h_check_ptr[i + 1]; ++e)
+            if (desc->beta_slot[e] != desc->beta_slot[g->h_check_ptr[i]]) { d->beta_per_check = false; break; }
     if (!rc) rc = upload(&d->alpha_slot, desc->alpha_slot, (size_t)g->n);
     if (!rc && d->form == LDPC_C2V_RCQ) {
         d->n_levels = desc->n_levels; d->n_quant = desc->n_quantizers;

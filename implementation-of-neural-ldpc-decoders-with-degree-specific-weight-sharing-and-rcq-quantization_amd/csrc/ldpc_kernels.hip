@@ -155,7 +155,9 @@ __device__ __forceinline__ void store_masked(T *p, const Pack<T, VEC> &v, const 
 // FIRST: iteration 0 reads llr[var] instead of v2c (the reference's "initialize with
 // channel LLRs", neural_2d_decoder.py:153-157, folded into the first sweep).
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int FORM, bool FIRST, int NL = 0>
+// BPC (RCQ only): one beta per check -- only two outgoing (magnitude, sign) pairs exist per codeword, so the
+// multiply and the quantiser run twice per check and every edge just picks one of four precomputed codes.
+template <typename T, int VEC, int FORM, bool FIRST, int NL = 0, bool BPC = false>
 __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restrict__ src,
                                                    void *__restrict__ c2v_out,
                                                    const T *__restrict__ beta_row,
@@ -224,6 +226,53 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     }
     OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
 
+    if constexpr (FORM == FORM_RCQ && BPC) {
+        const float b = (float)beta_row[beta_slot[e0]];
+        auto level = [&](float mag) {
+            int lvl = 0;
+            if constexpr (NL > 0) {
+#pragma unroll
+                for (int q = 1; q < NL; ++q) lvl = (mag >= th[q]) ? q : lvl;
+            } else if (n_levels <= 8) {
+#pragma unroll
+                for (int q = 1; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;
+            } else {
+                for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
+            }
+            return lvl;
+        };
+        // cc[k][c]: byte 0 = code of candidate k when the other signs multiply to +, byte 1 when to -
+        // (code = (w < 0) * L + level(|w|), w = +-(b * min): the sign bit counts only for a non-zero magnitude)
+        unsigned cc1[VEC], cc2[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const float p1 = b * (float)m1[c], p2 = b * (float)m2[c];
+            const float a1 = __builtin_fabsf(p1), a2 = __builtin_fabsf(p2);
+            const unsigned l1 = (unsigned)level(a1), l2 = (unsigned)level(a2);
+            const unsigned s1 = signbit_of<float>(p1), s2 = signbit_of<float>(p2);
+            const unsigned z1 = a1 > 0.0f ? (unsigned)n_levels : 0u, z2 = a2 > 0.0f ? (unsigned)n_levels : 0u;
+            cc1[c] = (l1 + (s1 ? z1 : 0u)) | ((l1 + (s1 ? 0u : z1)) << 8);
+            cc2[c] = (l2 + (s2 ? z2 : 0u)) | ((l2 + (s2 ? 0u : z2)) << 8);
+        }
+#pragma unroll LDPC_CN_UNROLL
+        for (int t = 0; t < dc; ++t) {
+            Pack<T, VEC> re;
+            if (wide) {
+                const T *row = FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W;
+                re = ld<T, VEC>(row);
+            }
+            Pack<OutT, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const unsigned own = wide ? signbit_of<T>(re.x[c]) : ((sm[c] >> (t & 31)) & 1u);
+                const unsigned neg = par[c] ^ own;
+                const unsigned cc = (t == idx[c]) ? cc2[c] : cc1[c];
+                o.x[c] = (OutT)((cc >> (neg * 8u)) & 0xffu);
+            }
+            store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
+        }
+        return;
+    }
 #pragma unroll LDPC_CN_UNROLL
     for (int t = 0; t < dc; ++t) {
         const T b = beta_row[beta_slot[e0 + t]];
