@@ -153,7 +153,10 @@ template <typename T, int VEC>
 int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
 {
     const GraphDev g = d->g->dev();
-    const int cb = (g.m + kWavesPerBlock - 1) / kWavesPerBlock;
+    // small check degrees: two consecutive checks per wave (cn_sweep CPW), for the two forms the benchmarks use
+    const int cpw = (g.E < 8 * (long long)g.m && (d->form == LDPC_C2V_NMS || (d->form == LDPC_C2V_RCQ && d->n_levels == 4))) ? 2 : 1;
+    const int per_block = kWavesPerBlock * cpw;
+    const int cb = (g.m + per_block - 1) / per_block;
     if (cb == 0 || g.E == 0) return LDPC_OK;
     const dim3 grid((unsigned)((size_t)w.tiles * cb)), block(kBlock);
     const bool first = it == 0;
@@ -162,22 +165,29 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     const T *oa_row = d->oms_alpha ? (const T *)d->oms_alpha + (size_t)it * d->n_oms_alpha : nullptr;
     const float *thr = d->form == LDPC_C2V_RCQ ? d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels : nullptr;
     const uint64_t *done = use_done ? w.done : nullptr;
-#define LDPC_CN(FORM, FIRST)                                                                          \
-    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM, FIRST>), grid, block, 0, s, g, src, (void *)w.c2v,      \
+#define LDPC_CN_X(FORM, FIRST, NL_, BPC_, CPW_)                                                                       \
+    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM, FIRST, NL_, BPC_, CPW_>), grid, block, 0, s, g, src, (void *)w.c2v,    \
                        beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb)
+#define LDPC_CN(FORM, FIRST) LDPC_CN_X(FORM, FIRST, 0, false, 1)
     if (d->form == LDPC_C2V_NMS) {
-        if (first) LDPC_CN(FORM_NMS, true); else LDPC_CN(FORM_NMS, false);
+        if (cpw == 2) { if (first) LDPC_CN_X(FORM_NMS, true, 0, false, 2); else LDPC_CN_X(FORM_NMS, false, 0, false, 2); }
+        else { if (first) LDPC_CN(FORM_NMS, true); else LDPC_CN(FORM_NMS, false); }
     } else if (d->form == LDPC_C2V_OMS) {
         if (first) LDPC_CN(FORM_OMS, true); else LDPC_CN(FORM_OMS, false);
     } else {
         if constexpr (sizeof(T) == 4) {
             if (d->n_levels == 4) {                      // bc = 3: compare chain with a compile-time length
-#define LDPC_CN_RCQ4(FIRST_, BPC_)                                                                                  \
-    hipLaunchKernelGGL((cn_sweep<T, VEC, FORM_RCQ, FIRST_, 4, BPC_>), grid, block, 0, s, g, src, (void *)w.c2v,       \
-                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb)
-                if (d->beta_per_check) { if (first) LDPC_CN_RCQ4(true, true); else LDPC_CN_RCQ4(false, true); }
-                else { if (first) LDPC_CN_RCQ4(true, false); else LDPC_CN_RCQ4(false, false); }
-#undef LDPC_CN_RCQ4
+                const int variant = (d->beta_per_check ? 2 : 0) + (cpw == 2 ? 1 : 0);
+                switch (variant * 2 + (first ? 1 : 0)) {
+                case 0: LDPC_CN_X(FORM_RCQ, false, 4, false, 1); break;
+                case 1: LDPC_CN_X(FORM_RCQ, true, 4, false, 1); break;
+                case 2: LDPC_CN_X(FORM_RCQ, false, 4, false, 2); break;
+                case 3: LDPC_CN_X(FORM_RCQ, true, 4, false, 2); break;
+                case 4: LDPC_CN_X(FORM_RCQ, false, 4, true, 1); break;
+                case 5: LDPC_CN_X(FORM_RCQ, true, 4, true, 1); break;
+                case 6: LDPC_CN_X(FORM_RCQ, false, 4, true, 2); break;
+                default: LDPC_CN_X(FORM_RCQ, true, 4, true, 2); break;
+                }
             } else {
                 if (first) LDPC_CN(FORM_RCQ, true); else LDPC_CN(FORM_RCQ, false);
             }
@@ -185,6 +195,7 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
             return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");
         }
     }
+#undef LDPC_CN_X
 #undef LDPC_CN
     HIP_TRY(hipGetLastError());
     return LDPC_OK;

@@ -157,7 +157,9 @@ __device__ __forceinline__ void store_masked(T *p, const Pack<T, VEC> &v, const 
 // ------------------------------------------------------------------------------------------
 // BPC (RCQ only): one beta per check -- only two outgoing (magnitude, sign) pairs exist per codeword, so the
 // multiply and the quantiser run twice per check and every edge just picks one of four precomputed codes.
-template <typename T, int VEC, int FORM, bool FIRST, int NL = 0, bool BPC = false>
+// CPW: consecutive checks one wave walks.  2 amortises the wave prologue (latch word, thresholds, row bases) on
+// graphs of small check degree (+3 % on the dc 4-7 code); on the dc ~ 13 code it costs 2-6 %, so the host picks.
+template <typename T, int VEC, int FORM, bool FIRST, int NL = 0, bool BPC = false, int CPW = 1>
 __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restrict__ src,
                                                    void *__restrict__ c2v_out,
                                                    const T *__restrict__ beta_row,
@@ -171,16 +173,25 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     using OutT = typename std::conditional<FORM == FORM_RCQ, uint8_t, T>::type;
     const int lane = threadIdx.x & (kWave - 1);
     const int tile = uni(blockIdx.x / check_blocks);
-    const int i = uni((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
-    if (i >= g.m) return;
-    const int e0 = uni(g.check_ptr[i]);
-    const int dc = uni(g.check_ptr[i + 1]) - e0;
-    if (dc == 0) return;
+    const int ibase = uni(((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
+    if (ibase >= g.m) return;
 
     Frozen<VEC> fz;
     if (load_frozen<VEC>(done, tile, lane, fz)) return;
-
+    float th[8];
+    if (FORM == FORM_RCQ) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
+    }
     const size_t lane_off = (size_t)lane * VEC;
+
+#pragma unroll
+    for (int cc_ = 0; cc_ < CPW; ++cc_) {
+    const int i = ibase + cc_;
+    if (i >= g.m) break;
+    const int e0 = uni(g.check_ptr[i]);
+    const int dc = uni(g.check_ptr[i + 1]) - e0;
+    if (dc == 0) continue;
     const T *in_base = FIRST ? src + (size_t)tile * g.n * W + lane_off
                              : src + ((size_t)tile * g.E + e0) * W + lane_off;
 
@@ -218,12 +229,6 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     }
 
     const bool wide = dc > 32;   // sign masks hold 32 edges; wider checks re-read their inputs
-    // quantiser thresholds: up to 8 levels (bc <= 4) live in SGPRs; NaN padding never matches
-    float th[8];
-    if (FORM == FORM_RCQ) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
-    }
     OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
 
     if constexpr (FORM == FORM_RCQ && BPC) {
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
             }
             store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
         }
-        return;
+        continue;
     }
 #pragma unroll LDPC_CN_UNROLL
     for (int t = 0; t < dc; ++t) {
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
         }
         store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
     }
+    }   // checks of this wave
 }
 
 // ------------------------------------------------------------------------------------------
