@@ -59,169 +59,151 @@ class TrainingConfig:
 
 
 def _grad_norm(model: nn.Module) -> float:
-    total = 0.0
-    for p in model.parameters():
-        if p.grad is not None:
-            total += p.grad.data.norm(2).item() ** 2
-    return total ** 0.5
+    """l2 norm over every parameter gradient that exists"""
+    sq = [float(p.grad.detach().pow(2).sum()) for p in model.parameters() if p.grad is not None]
+    return float(np.sqrt(sum(sq))) if sq else 0.0
+
+
+def _frames_right(decoded: torch.Tensor, targets: torch.Tensor) -> int:
+    return int((decoded == targets).all(dim=1).sum().item())
+
+
+def _plot_series(panels, figsize, save_path):
+    """panels: [(kind, data, title, xlabel, ylabel)], kind in {"line", "hist", "scatter"}"""
+    import matplotlib.pyplot as plt
+    fig, axes = plt.subplots(1, len(panels), figsize=figsize)
+    for ax, (kind, data, title, xlabel, ylabel) in zip(np.atleast_1d(axes), panels):
+        if kind == "line":
+            ax.plot(data)
+        elif kind == "hist":
+            ax.hist(data, bins=20, alpha=0.7)
+        else:
+            ax.scatter(data[0], data[1], alpha=0.6)
+        ax.set(title=title, xlabel=xlabel, ylabel=ylabel)
+        ax.grid(True)
+    fig.tight_layout()
+    if save_path:
+        fig.savefig(save_path)
+    plt.show()
 
 
 class PosteriorJointTrainer:
-    """Trainer implementing posterior joint training (loss on the returned posterior only)"""
+    """Posterior joint training: Adam on the BCE of the posterior the decoder returns (no per-iteration losses)."""
 
     def __init__(self, model: nn.Module, config: TrainingConfig):
-        self.model = model
-        self.config = config
+        self.model, self.config = model, config
         self.device = torch.device(config.device)
         self.model.to(self.device)
         self.optimizer = optim.Adam(self.model.parameters(), lr=config.learning_rate)
         self.train_losses: List[float] = []
         self.train_accuracies: List[float] = []
         self.gradient_norms: List[float] = []
-        logger.info(f"Initialized trainer with {sum(p.numel() for p in model.parameters())} parameters")
+        logger.info("trainer ready: %d trainable scalars", sum(p.numel() for p in model.parameters()))
 
+    # ---- data ------------------------------------------------------------------------------------------
     def generate_training_data(self, code: LDPCCode, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """All-zero codewords through AWGN, one SNR per sample on linspace(snr_min, snr_max) (:57-84)."""
-        codewords = torch.zeros(num_samples, code.n, dtype=torch.float32)
-        snr_min, snr_max = self.config.snr_range
-        snrs = torch.linspace(snr_min, snr_max, num_samples)
-        if self.config.llr_convention == "reference":
-            llrs = torch.zeros_like(codewords)
-            for i in range(num_samples):
-                llrs[i] = torch.tensor(simulate_awgn_channel(codewords[i].numpy(), snrs[i].item()), dtype=torch.float32)
-            return llrs, codewords
+        """(llrs [N, n], targets [N, n]): all-zero codewords over AWGN, sample i at SNR linspace(lo, hi, N)[i]
+        (training_framework.py:57-84)"""
+        targets = torch.zeros(num_samples, code.n, dtype=torch.float32)
+        lo, hi = self.config.snr_range
+        snr_db = torch.linspace(lo, hi, num_samples)
+        if self.config.llr_convention == "reference":          # the reference's channel helper, one call per sample
+            rows = [torch.as_tensor(simulate_awgn_channel(targets[i].numpy(), float(snr_db[i])), dtype=torch.float32)
+                    for i in range(num_samples)]
+            llrs = torch.stack(rows) if rows else torch.zeros_like(targets)
+            return llrs, targets
         gen = torch.Generator()
-        if self.config.seed is not None:
-            gen.manual_seed(int(self.config.seed))
-        else:
+        if self.config.seed is None:
             gen.seed()
-        sigma2 = 10.0 ** (-snrs.double() / 10.0)                       # noise variance at unit symbol energy
-        z = torch.randn(num_samples, code.n, generator=gen, dtype=torch.float64)
-        llrs = 2.0 * (1.0 + sigma2.sqrt().unsqueeze(1) * z) / sigma2.unsqueeze(1)
-        return llrs.to(torch.float32), codewords
+        else:
+            gen.manual_seed(int(self.config.seed))
+        var = torch.pow(10.0, -snr_db.double() / 10.0).unsqueeze(1)            # noise variance at unit symbol energy
+        noise = torch.randn(num_samples, code.n, generator=gen, dtype=torch.float64)
+        return (2.0 * (1.0 + var.sqrt() * noise) / var).float(), targets
 
     def compute_loss(self, outputs: torch.Tensor, targets: torch.Tensor, posteriors: torch.Tensor) -> torch.Tensor:
-        """binary cross entropy of the posterior LLRs against the transmitted bits (:86-104)"""
-        return F.binary_cross_entropy_with_logits(-posteriors, targets.float())
+        """BCE-with-logits of -posterior against the transmitted bits (training_framework.py:101); `outputs` unused"""
+        return F.binary_cross_entropy_with_logits(posteriors.neg(), targets.to(posteriors.dtype))
+
+    # ---- one pass over a loader ----------------------------------------------------------------------------
+    def _pass(self, loader: DataLoader, train: bool) -> Tuple[float, float, float]:
+        self.model.train(train)
+        loss_sum, right, seen, norms = 0.0, 0, 0, []
+        for step, (llrs, targets) in enumerate(loader):
+            llrs, targets = llrs.to(self.device), targets.to(self.device)
+            with torch.set_grad_enabled(train):
+                decoded, posteriors, _ = self.model(llrs)
+                loss = self.compute_loss(decoded, targets, posteriors)
+            if train:
+                self.optimizer.zero_grad()
+                loss.backward()                                 # HIP backward sweeps (autograd_bridge.py)
+                if self.config.data_parallel:                   # every rank trained on its own shard
+                    import sharding
+                    sharding.all_reduce_gradients(self.model.parameters())
+                norms.append(_grad_norm(self.model))
+                if self.config.use_gradient_clipping:
+                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config.clip_threshold)
+                self.optimizer.step()
+                if step % 10 == 0:
+                    logger.info("step %d: loss %.6f, |grad| %.6f", step, loss.item(), norms[-1])
+            loss_sum += float(loss.item())
+            right += _frames_right(decoded, targets)
+            seen += llrs.shape[0]
+        batches = max(len(loader), 1)
+        return loss_sum / batches, right / max(seen, 1), (float(np.mean(norms)) if norms else 0.0)
 
     def train_epoch(self, train_loader: DataLoader) -> Tuple[float, float, float]:
-        self.model.train()
-        total_loss, total_correct, total_samples = 0.0, 0, 0
-        epoch_grad_norms = []
-        for batch_idx, (llrs, targets) in enumerate(train_loader):
-            llrs, targets = llrs.to(self.device), targets.to(self.device)
-            self.optimizer.zero_grad()
-            decoded, posteriors, iterations = self.model(llrs)
-            loss = self.compute_loss(decoded, targets, posteriors)
-            loss.backward()
-            if self.config.data_parallel:              # each rank trained on its own shard of the batch
-                import sharding
-                sharding.all_reduce_gradients(self.model.parameters())
-            total_norm = _grad_norm(self.model)
-            epoch_grad_norms.append(total_norm)
-            if self.config.use_gradient_clipping:
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config.clip_threshold)
-            self.optimizer.step()
-            correct = (decoded == targets).all(dim=1).sum().item()
-            total_correct += correct
-            total_samples += llrs.size(0)
-            total_loss += loss.item()
-            if batch_idx % 10 == 0:
-                logger.info(f"Batch {batch_idx}, Loss: {loss.item():.6f}, "
-                            f"Grad Norm: {total_norm:.6f}, Acc: {correct / llrs.size(0):.4f}")
-        avg_grad_norm = float(np.mean(epoch_grad_norms)) if epoch_grad_norms else 0.0
-        return total_loss / max(len(train_loader), 1), total_correct / max(total_samples, 1), avg_grad_norm
+        """-> (mean loss, frame accuracy, mean gradient norm)"""
+        return self._pass(train_loader, train=True)
+
+    def validate(self, val_loader: DataLoader) -> Tuple[float, float, float]:
+        """-> (mean loss, frame accuracy, 0.0)"""
+        return self._pass(val_loader, train=False)
 
     def train(self, code: LDPCCode, num_train_samples: int = 1000, num_val_samples: int = 200) -> Dict[str, List[float]]:
-        logger.info("Generating training data...")
-        train_llrs, train_targets = self.generate_training_data(code, num_train_samples)
-        val_llrs, val_targets = self.generate_training_data(code, num_val_samples)
-        train_loader = DataLoader(TensorDataset(train_llrs, train_targets), batch_size=self.config.batch_size, shuffle=True)
-        val_loader = DataLoader(TensorDataset(val_llrs, val_targets), batch_size=self.config.batch_size, shuffle=False)
-        logger.info(f"Starting training for {self.config.num_epochs} epochs...")
+        bs = self.config.batch_size
+        train_loader = DataLoader(TensorDataset(*self.generate_training_data(code, num_train_samples)), batch_size=bs, shuffle=True)
+        val_loader = DataLoader(TensorDataset(*self.generate_training_data(code, num_val_samples)), batch_size=bs, shuffle=False)
         for epoch in range(self.config.num_epochs):
-            start_time = time.time()
-            train_loss, train_acc, train_grad_norm = self.train_epoch(train_loader)
-            val_loss, val_acc, _ = self.validate(val_loader)
-            self.train_losses.append(train_loss)
-            self.train_accuracies.append(train_acc)
-            self.gradient_norms.append(train_grad_norm)
-            logger.info(f"Epoch {epoch + 1}/{self.config.num_epochs}: "
-                        f"Train Loss: {train_loss:.6f}, Train Acc: {train_acc:.4f}, "
-                        f"Val Loss: {val_loss:.6f}, Val Acc: {val_acc:.4f}, "
-                        f"Grad Norm: {train_grad_norm:.6f}, Time: {time.time() - start_time:.2f}s")
-            if train_acc > 0.99:                                     # :222-224
-                logger.info(f"Early stopping at epoch {epoch + 1} due to high accuracy")
+            t0 = time.time()
+            loss, acc, gnorm = self.train_epoch(train_loader)
+            vloss, vacc, _ = self.validate(val_loader)
+            self.train_losses.append(loss)
+            self.train_accuracies.append(acc)
+            self.gradient_norms.append(gnorm)
+            logger.info("epoch %d/%d: train loss %.6f acc %.4f | val loss %.6f acc %.4f | |grad| %.6f | %.2f s",
+                        epoch + 1, self.config.num_epochs, loss, acc, vloss, vacc, gnorm, time.time() - t0)
+            if acc > 0.99:                                       # the reference's stop rule (:222-224)
                 break
         return {"train_losses": self.train_losses, "train_accuracies": self.train_accuracies,
                 "gradient_norms": self.gradient_norms}
 
-    def validate(self, val_loader: DataLoader) -> Tuple[float, float, float]:
-        self.model.eval()
-        total_loss, total_correct, total_samples = 0.0, 0, 0
-        with torch.no_grad():
-            for llrs, targets in val_loader:
-                llrs, targets = llrs.to(self.device), targets.to(self.device)
-                decoded, posteriors, iterations = self.model(llrs)
-                total_loss += self.compute_loss(decoded, targets, posteriors).item()
-                total_correct += (decoded == targets).all(dim=1).sum().item()
-                total_samples += llrs.size(0)
-        return total_loss / max(len(val_loader), 1), total_correct / max(total_samples, 1), 0.0
-
     def plot_training_history(self, save_path: Optional[str] = None):
-        import matplotlib.pyplot as plt
-        fig, axes = plt.subplots(1, 3, figsize=(15, 5))
-        for ax, series, title, ylabel in ((axes[0], self.train_losses, "Training Loss", "Loss"),
-                                          (axes[1], self.train_accuracies, "Training Accuracy", "Accuracy"),
-                                          (axes[2], self.gradient_norms, "Gradient Norms", "Gradient Norm")):
-            ax.plot(series)
-            ax.set_title(title)
-            ax.set_xlabel("Epoch")
-            ax.set_ylabel(ylabel)
-            ax.grid(True)
-        plt.tight_layout()
-        if save_path:
-            plt.savefig(save_path)
-        plt.show()
+        _plot_series([("line", self.train_losses, "Training Loss", "Epoch", "Loss"),
+                      ("line", self.train_accuracies, "Training Accuracy", "Epoch", "Accuracy"),
+                      ("line", self.gradient_norms, "Gradient Norms", "Epoch", "Gradient Norm")], (15, 5), save_path)
 
 
 class GradientExplosionAnalyzer:
-    """Gradient magnitudes of the decoder for random inputs (:293-378)"""
+    """Distribution of the decoder's gradient norm over random inputs (training_framework.py:293-378)."""
 
     def __init__(self, model: nn.Module, code: LDPCCode):
-        self.model = model
-        self.code = code
+        self.model, self.code = model, code
 
     def analyze_gradient_explosion(self, num_samples: int = 100) -> Dict[str, List[float]]:
         self.model.eval()
-        gradient_magnitudes, iteration_gradients = [], []
+        norms, iteration_counts = [], []
         for _ in range(num_samples):
-            llr = torch.randn(self.code.n) * 2
-            decoded, posteriors, iterations = self.model(llr)
-            loss = F.binary_cross_entropy_with_logits(-posteriors, torch.zeros_like(decoded).float())
-            if posteriors.requires_grad:        # no parameter on the path (e.g. sharing type 4 stopping at once): gradient 0
-                loss.backward()
-            gradient_magnitudes.append(_grad_norm(self.model))
-            iteration_gradients.append(iterations)
+            decoded, posterior, iterations = self.model(2.0 * torch.randn(self.code.n))
+            if posterior.requires_grad:     # no parameter on the path (e.g. sharing type 4 stopping at once): norm 0
+                F.binary_cross_entropy_with_logits(posterior.neg(), torch.zeros_like(posterior)).backward()
+            norms.append(_grad_norm(self.model))
+            iteration_counts.append(iterations)
             self.model.zero_grad()
-        return {"gradient_magnitudes": gradient_magnitudes, "iteration_counts": iteration_gradients,
-                "mean_gradient": np.mean(gradient_magnitudes), "std_gradient": np.std(gradient_magnitudes),
-                "max_gradient": np.max(gradient_magnitudes)}
+        return {"gradient_magnitudes": norms, "iteration_counts": iteration_counts,
+                "mean_gradient": np.mean(norms), "std_gradient": np.std(norms), "max_gradient": np.max(norms)}
 
     def plot_gradient_analysis(self, results: Dict[str, List[float]], save_path: Optional[str] = None):
-        import matplotlib.pyplot as plt
-        fig, axes = plt.subplots(1, 2, figsize=(12, 5))
-        axes[0].hist(results["gradient_magnitudes"], bins=20, alpha=0.7)
-        axes[0].set_title("Gradient Magnitude Distribution")
-        axes[0].set_xlabel("Gradient Magnitude")
-        axes[0].set_ylabel("Frequency")
-        axes[0].grid(True)
-        axes[1].scatter(results["iteration_counts"], results["gradient_magnitudes"], alpha=0.6)
-        axes[1].set_title("Gradient Magnitude vs Iterations")
-        axes[1].set_xlabel("Iterations")
-        axes[1].set_ylabel("Gradient Magnitude")
-        axes[1].grid(True)
-        plt.tight_layout()
-        if save_path:
-            plt.savefig(save_path)
-        plt.show()
+        _plot_series([("hist", results["gradient_magnitudes"], "Gradient Magnitude Distribution", "Gradient Magnitude", "Frequency"),
+                      ("scatter", (results["iteration_counts"], results["gradient_magnitudes"]),
+                       "Gradient Magnitude vs Iterations", "Iterations", "Gradient Magnitude")], (12, 5), save_path)
