@@ -112,6 +112,7 @@ int pick_vec(const ldpc_decoder *d, int64_t batch)
 struct Workspace {
     int vec = 0, tiles = 0;
     char *llrT = nullptr, *v2c = nullptr, *c2v = nullptr, *postT = nullptr;
+    char *c2v_prev = nullptr;        // saving forward only: previous iteration's c2v slice (latched rows are carried over)
     uint64_t *bitsT = nullptr, *done = nullptr;
     int *iters = nullptr;
     size_t total = 0;
@@ -167,7 +168,8 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     const uint64_t *done = use_done ? w.done : nullptr;
 #define LDPC_CN_X(FORM, FIRST, NL_, BPC_, CPW_)                                                                       \
     hipLaunchKernelGGL((cn_sweep<T, VEC, FORM, FIRST, NL_, BPC_, CPW_>), grid, block, 0, s, g, src, (void *)w.c2v,    \
-                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb)
+                       beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb,             \
+                       (const void *)w.c2v_prev)
 #define LDPC_CN(FORM, FIRST) LDPC_CN_X(FORM, FIRST, 0, false, 1)
     if (d->form == LDPC_C2V_NMS) {
         if (cpw == 2) { if (first) LDPC_CN_X(FORM_NMS, true, 0, false, 2); else LDPC_CN_X(FORM_NMS, false, 0, false, 2); }
@@ -301,21 +303,23 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         if (rc) return rc;
     }
     for (int it = 0; it < T_it; ++it) {
-        int rc = launch_cn<T, VEC>(d, w, it, early_stop, s);
-        if (rc) return rc;
-        // training forward: keep this iteration's c2v rows, and the v2c rows the next one will read, in `saved`
-        // (layout: SavedLayout).  Copies of the working buffers, because a stopped codeword's rows must stay
-        // latched in the working buffers -- the final variable sweep forms its posterior from them.
-        const size_t msg_bytes = (size_t)w.tiles * W * g.E * sizeof(T);
-        SavedLayout sl;
+        // training forward: iteration `it` writes its c2v rows, and the v2c rows the next one reads, straight into
+        // their slices of `saved` (SavedLayout).  A stopped codeword's rows stay latched because the check sweep
+        // carries them over from the previous slice -- the final variable sweep forms its posterior from them.
+        Workspace wc = w, wv = w;
         if (saved) {
-            sl = saved_layout(d, w.tiles, W);
-            HIP_TRY(hipMemcpyAsync(saved + sl.c2v_off(it), w.c2v, msg_bytes, hipMemcpyDeviceToDevice, s));
+            const SavedLayout sl = saved_layout(d, w.tiles, W);
+            wc.c2v = wv.c2v = saved + sl.c2v_off(it);
+            if (it > 0) {
+                wc.v2c = saved + sl.v2c_off(it);
+                if (early_stop) wc.c2v_prev = saved + sl.c2v_off(it - 1);
+            }
+            if (it + 1 < T_it) wv.v2c = saved + sl.v2c_off(it + 1);
         }
-        rc = launch_vn<T, VEC>(d, w, it, it == T_it - 1, early_stop, s);
+        int rc = launch_cn<T, VEC>(d, wc, it, early_stop, s);
         if (rc) return rc;
-        if (saved && it + 1 < T_it)
-            HIP_TRY(hipMemcpyAsync(saved + sl.v2c_off(it + 1), w.v2c, msg_bytes, hipMemcpyDeviceToDevice, s));
+        rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s);
+        if (rc) return rc;
         if (early_stop) {
             hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
                                w.iters, it + 1, 1);

@@ -148,6 +148,24 @@ __device__ __forceinline__ void store_masked(T *p, const Pack<T, VEC> &v, const 
     }
 }
 
+// Training forward (ldpc_decode_saving): every iteration writes its own slice, so a stopped codeword's latched
+// values are carried forward from the previous iteration's slice instead of being left in place.
+template <typename T, int VEC>
+__device__ __forceinline__ void store_latched(T *p, const T *prev, Pack<T, VEC> v, const Frozen<VEC> &f)
+{
+    if (!prev) {
+        store_masked<T, VEC>(p, v, f);
+        return;
+    }
+    if (!f.none()) {
+        const Pack<T, VEC> old = ld<T, VEC>(prev);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            if (f.one(c)) v.x[c] = old.x[c];
+    }
+    st<T, VEC>(p, v);
+}
+
 // ------------------------------------------------------------------------------------------
 // Check-node (CN -> VN) sweep.  One wave = one check x W codewords.
 //   pass 1: stream the dc incoming rows, keep min1/min2/arg-min and the sign bits
@@ -167,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
                                                    const float *__restrict__ thr, int n_levels,
                                                    const T *__restrict__ oms_alpha_row,
                                                    const int *__restrict__ oms_alpha_slot,
-                                                   const uint64_t *__restrict__ done, int check_blocks)
+                                                   const uint64_t *__restrict__ done, int check_blocks,
+                                                   const void *__restrict__ prev_out = nullptr)
 {
     constexpr int W = kWave * VEC;
     using OutT = typename std::conditional<FORM == FORM_RCQ, uint8_t, T>::type;
@@ -177,7 +196,8 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     if (ibase >= g.m) return;
 
     Frozen<VEC> fz;
-    if (load_frozen<VEC>(done, tile, lane, fz)) return;
+    const bool all_frozen = load_frozen<VEC>(done, tile, lane, fz);
+    if (all_frozen && !prev_out) return;
     float th[8];
     if (FORM == FORM_RCQ) {
 #pragma unroll
@@ -192,6 +212,13 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     const int e0 = uni(g.check_ptr[i]);
     const int dc = uni(g.check_ptr[i + 1]) - e0;
     if (dc == 0) continue;
+    if (all_frozen) {                              // saving mode: carry the tile's latched rows into this slice
+        const size_t off = ((size_t)tile * g.E + e0) * W + (size_t)lane * VEC;
+        for (int t = 0; t < dc; ++t)
+            st<OutT, VEC>(reinterpret_cast<OutT *>(c2v_out) + off + (size_t)t * W,
+                          ld<OutT, VEC>(reinterpret_cast<const OutT *>(prev_out) + off + (size_t)t * W));
+        continue;
+    }
     const T *in_base = FIRST ? src + (size_t)tile * g.n * W + lane_off
                              : src + ((size_t)tile * g.E + e0) * W + lane_off;
 
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
 
     const bool wide = dc > 32;   // sign masks hold 32 edges; wider checks re-read their inputs
     OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
+    const OutT *prev_base = prev_out ? reinterpret_cast<const OutT *>(prev_out) + ((size_t)tile * g.E + e0) * W + lane_off : nullptr;
 
     if constexpr (FORM == FORM_RCQ && BPC) {
         const float b = (float)beta_row[beta_slot[e0]];
@@ -274,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
                 const unsigned cc = (t == idx[c]) ? cc2[c] : cc1[c];
                 o.x[c] = (OutT)((cc >> (neg * 8u)) & 0xffu);
             }
-            store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
+            store_latched<OutT, VEC>(out_base + (size_t)t * W, prev_base ? prev_base + (size_t)t * W : nullptr, o, fz);
         }
         continue;
     }
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
                 o.x[c] = (OutT)code;
             }
         }
-        store_masked<OutT, VEC>(out_base + (size_t)t * W, o, fz);
+        store_latched<OutT, VEC>(out_base + (size_t)t * W, prev_base ? prev_base + (size_t)t * W : nullptr, o, fz);
     }
     }   // checks of this wave
 }
