@@ -371,10 +371,16 @@ int decode_dispatch(const ldpc_decoder *d, const void *llr, int64_t batch, bool 
 // alpha table identically 1.0f / every quantiser's tau_0 == 0: exact shortcuts in the resident kernel
 void resident_table_flags(ldpc_decoder *d, const void *alpha_host, const float *thr_host)
 {
-    if (alpha_host && d->dtype == LDPC_F32) {
-        const float *a = (const float *)alpha_host;
+    if (alpha_host) {
+        const size_t cnt = (size_t)std::max(d->T, 0) * d->n_alpha;
         bool unit = true;
-        for (size_t k = 0; k < (size_t)std::max(d->T, 0) * d->n_alpha; ++k) unit = unit && a[k] == 1.0f;
+        if (d->dtype == LDPC_F32) {
+            const float *a = (const float *)alpha_host;
+            for (size_t k = 0; k < cnt; ++k) unit = unit && a[k] == 1.0f;
+        } else {
+            const double *a = (const double *)alpha_host;
+            for (size_t k = 0; k < cnt; ++k) unit = unit && a[k] == 1.0;
+        }
         d->unit_alpha = unit;
     }
     if (thr_host) {
@@ -400,6 +406,7 @@ int plan_upload(ldpc_decoder *d, const X **dst, const std::vector<X> &src)
 
 int resident_alpha_floats(const ldpc_decoder *d)
 {
+    if (d->dtype != LDPC_F32) return 0;                 // the fp64 kernel reads alpha from global memory
     const long long cnt = (long long)d->T * d->n_alpha;
     return cnt <= kResAlphaMax ? (int)cnt : 0;
 }
@@ -486,7 +493,11 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
 {
     const ldpc_graph *g = d->g;
     d->res_ok = false;
-    if (d->dtype != LDPC_F32 || g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
+    if (g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
+    // fp64 (the reference's BasicMinSumDecoder dtype): the normalised form with one factor per check; a codeword's
+    // 8-byte slots take the place of a float codeword PAIR, so the geometry below must come out at G = 2
+    const bool f64 = d->dtype == LDPC_F64;
+    if (f64 && (d->form != LDPC_C2V_NMS || !d->beta_per_check)) return LDPC_OK;
     const int n = g->n, m = g->m;
     if (n > 65535 || d->n_beta > 65535 || d->n_alpha >= (1 << 24) || d->n_oms_alpha > 65535) return LDPC_OK;
 
@@ -510,6 +521,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     };
     int G = 0, blocks = 0, mstride = m;
     if (!geometry(m, G, blocks)) return LDPC_OK;
+    if (f64 && G != 2) return LDPC_OK;
     if (m <= 512) {
         int G5 = 0, b5 = 0;
         if (geometry(512, G5, b5) && G5 == G && std::min(b5, 2) == std::min(blocks, 2)) { mstride = 512; blocks = b5; }
@@ -588,8 +600,23 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
 template <int G>
 int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
 {
-    const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
     size_t lds = d->res_lds;
+    if (d->dtype == LDPC_F64) {                       // one fp64 codeword per workgroup in the slots of a float pair
+        if (G != 2 || !d->res.bslot_c) return fail(LDPC_ERR_ARG, "internal: fp64 resident geometry");
+        const unsigned blocks64 = (unsigned)a.batch;
+#define LDPC_RES64(MS)                                                                                    \
+    do {                                                                                                  \
+        auto kfn = a.early_stop ? resident_decode<1, FORM_NMS, true, 0, MS, 1, double>                    \
+                                : resident_decode<1, FORM_NMS, true, 0, MS, 0, double>;                   \
+        HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, dim3(blocks64), dim3(d->res_NT), lds, s, d->res, a);                      \
+    } while (0)
+        if (d->res.mstride == 512) LDPC_RES64(512); else LDPC_RES64(0);
+#undef LDPC_RES64
+        HIP_TRY(hipGetLastError());
+        return LDPC_OK;
+    }
+    const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
     { const char *pad = getenv("LDPC_RES_LDS_PAD"); if (pad && atoi(pad) > 0) lds = std::min<size_t>(lds + atoi(pad), 160 * 1024); }  // occupancy experiments
 #define LDPC_RES_MS(FORM, NL, MS)                                                                        \
     do {                                                                                                 \
@@ -829,7 +856,7 @@ int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4])
 {
     if (!d || !out4) return fail(LDPC_ERR_ARG, "NULL argument");
     out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : LDPC_MODE_STREAM;
-    out4[1] = d->res_ok ? d->res_G : 0;
+    out4[1] = d->res_ok ? (d->dtype == LDPC_F64 ? 1 : d->res_G) : 0;      // fp64: one codeword in a float pair's slots
     out4[2] = d->res_ok ? d->res_NT : 0;
     out4[3] = d->res_ok ? (int32_t)d->res_lds : 0;
     return LDPC_OK;

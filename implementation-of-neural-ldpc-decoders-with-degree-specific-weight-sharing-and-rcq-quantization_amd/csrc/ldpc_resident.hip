@@ -128,17 +128,56 @@ __device__ __forceinline__ float res_quant_rec(float mag, const float (&th)[8], 
     return rec;
 }
 
-template <int G, int FORM, bool BPC, bool UNI, int NL, int MS>
+template <int G, int FORM, bool BPC, bool UNI, int NL, int MS, typename T>
 __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned char *smem, int p, int dc, int dcw,
-                                               float b_check, const float *__restrict__ beta_row,
-                                               const float *__restrict__ oa_row, const float (&th)[8],
+                                               T b_check, const T *__restrict__ beta_row,
+                                               const T *__restrict__ oa_row, const float (&th)[8],
                                                const float *__restrict__ thr, int n_levels, bool rcq_zero0)
 {
-    using P = Pack<float, G>;
-    constexpr int kEl = G * 4;
+    constexpr int kEl = G * (int)sizeof(T);
     const int trip = UNI ? dcw : dc;
     const unsigned stride = (MS > 0 ? (unsigned)MS : (unsigned)pl.mstride) * kEl;   // compile-time when MS > 0
     const unsigned base = (unsigned)p * kEl;
+    if constexpr (!std::is_same<T, float>::value) {
+        // fp64 (BasicMinSumDecoder with the reference's own float64 LLRs): normalised min-sum with one factor per
+        // check, the same two passes in plain compare/select form (v_med3 / v_bitop3 are 32-bit instructions)
+        static_assert(FORM == FORM_NMS && BPC, "the fp64 resident engine covers the per-check normalised form");
+        using PD = Pack<T, G>;
+        T m1[G], m2[G];
+        unsigned par[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { m1[g] = inf_of<T>(); m2[g] = inf_of<T>(); par[g] = 0; }
+#pragma unroll 4
+        for (int t = 0; t < trip; ++t) {
+            const PD v = lds_load<PD>(base + t * stride);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const T a = abs_of<T>(v.x[g]);
+                par[g] ^= signbit_of<T>(v.x[g]);
+                if (a < m1[g]) { m2[g] = m1[g]; m1[g] = a; }
+                else if (a < m2[g]) { m2[g] = a; }
+            }
+        }
+        T o1[G], o2[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (trip == 1) m2[g] = m1[g];                   // "min2_val = min_val" for a degree-1 check
+            o1[g] = flip_sign<T>(b_check * m1[g], par[g]);
+            o2[g] = flip_sign<T>(b_check * m2[g], par[g]);
+        }
+#pragma unroll 4
+        for (int t = 0; t < trip; ++t) {
+            const unsigned addr = base + t * stride;
+            const PD v = lds_load<PD>(addr);
+            PD o;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                o.x[g] = flip_sign<T>((abs_of<T>(v.x[g]) == m1[g]) ? o2[g] : o1[g], signbit_of<T>(v.x[g]));
+            lds_store<PD>(addr, o);
+        }
+        return;
+    } else {
+    using P = Pack<float, G>;
     float m1[G], m2[G];
     uint32_t sacc[G];
     unsigned nz[G];
@@ -241,16 +280,17 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
         lds_store<P>(addr, o);
         slot += sstride;
     }
+    }   // fp32
 }
 
 // `dc_pre` / `b_pre` are the first round's degree and per-check beta, fetched by the caller ahead of
 // the barrier so their global-memory latency is off the critical path.
-template <int G, int FORM, bool BPC, int NL, int MS>
+template <int G, int FORM, bool BPC, int NL, int MS, typename T>
 __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned char *smem,
-                                                const float *__restrict__ beta_row,
-                                                const float *__restrict__ oa_row,
+                                                const T *__restrict__ beta_row,
+                                                const T *__restrict__ oa_row,
                                                 const float *__restrict__ thr, int n_levels, bool rcq_zero0,
-                                                int dc_pre, float b_pre, int tid, int nt)
+                                                int dc_pre, T b_pre, int tid, int nt)
 {
     float th[8];
     if (FORM == FORM_RCQ) {
@@ -258,16 +298,16 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
         for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
     }
     int dc = dc_pre;
-    float b_check = b_pre;
+    T b_check = b_pre;
     for (int p = tid; p < pl.m; p += nt) {
         if (p != tid) {
             dc = pl.dc_s[p];
-            b_check = BPC ? beta_row[pl.bslot_c[p]] : 0.0f;
+            b_check = BPC ? beta_row[pl.bslot_c[p]] : (T)0;
         }
         for (bool pending = true; pending;) {            // wave-uniform trip count per distinct degree (see res_var_phase)
             const int dcw = __builtin_amdgcn_readfirstlane(dc);
             if (dc == dcw) {
-                res_check_body<G, FORM, BPC, true, NL, MS>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+                res_check_body<G, FORM, BPC, true, NL, MS, T>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
                 pending = false;
             }
         }
@@ -281,12 +321,13 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
 //         (dead) LLR slot with the posterior so the output pass can read it in original order
 // MODE 4 / 6: MODE 0 / 2 plus the hard-decision byte from the same gathered values -- the early-stop
 //         iteration of callers that do not ask for the posterior (one gather pass instead of two)
-template <int G, int DV, int MODE>
-__device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restrict__ llr_s,
+template <int G, int DV, int MODE, typename T>
+__device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict__ llr_s,
                                              uint8_t *__restrict__ bits_s, int q, const uint4 &slo, const uint4 &shi,
-                                             float a, unsigned emask)
+                                             T a, unsigned emask)
 {
-    using P = Pack<float, G>;
+    using P = Pack<T, G>;
+    constexpr int ORD = std::is_same<T, float>::value ? 0 : 1;       // torch.sum fp32 order / np.sum fp64 order
     P *L = reinterpret_cast<P *>(llr_s);
     const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
     P x[DV > 0 ? DV : 1];
@@ -295,22 +336,22 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
     P l = L[q];
     if constexpr (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 6) {
         P out[DV > 0 ? DV : 1];
-        auto v2c = [&](float llr, float sum) { return (MODE & 2) ? llr + sum : llr + a * sum; };
+        auto v2c = [&](T llr, T sum) { return (MODE & 2) ? llr + sum : llr + a * sum; };
         unsigned byte = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float xs[DV > 0 ? DV : 1];
+            T xs[DV > 0 ? DV : 1];
 #pragma unroll
             for (int k = 0; k < DV; ++k) xs[k] = x[k].x[g];
-            if constexpr ((MODE & 4) != 0) byte |= ((l.x[g] + sum_ct<DV, -1, 0, float>(xs)) < 0.0f ? 1u : 0u) << g;
-            if constexpr (DV >= 1) out[0].x[g] = v2c(l.x[g], sum_ct<DV - 1, 0, 0, float>(xs));
-            if constexpr (DV >= 2) out[1].x[g] = v2c(l.x[g], sum_ct<DV - 1, 1, 0, float>(xs));
-            if constexpr (DV >= 3) out[2].x[g] = v2c(l.x[g], sum_ct<DV - 1, 2, 0, float>(xs));
-            if constexpr (DV >= 4) out[3].x[g] = v2c(l.x[g], sum_ct<DV - 1, 3, 0, float>(xs));
-            if constexpr (DV >= 5) out[4].x[g] = v2c(l.x[g], sum_ct<DV - 1, 4, 0, float>(xs));
-            if constexpr (DV >= 6) out[5].x[g] = v2c(l.x[g], sum_ct<DV - 1, 5, 0, float>(xs));
-            if constexpr (DV >= 7) out[6].x[g] = v2c(l.x[g], sum_ct<DV - 1, 6, 0, float>(xs));
-            if constexpr (DV >= 8) out[7].x[g] = v2c(l.x[g], sum_ct<DV - 1, 7, 0, float>(xs));
+            if constexpr ((MODE & 4) != 0) byte |= ((l.x[g] + sum_ct<DV, -1, ORD, T>(xs)) < (T)0 ? 1u : 0u) << g;
+            if constexpr (DV >= 1) out[0].x[g] = v2c(l.x[g], sum_ct<DV - 1, 0, ORD, T>(xs));
+            if constexpr (DV >= 2) out[1].x[g] = v2c(l.x[g], sum_ct<DV - 1, 1, ORD, T>(xs));
+            if constexpr (DV >= 3) out[2].x[g] = v2c(l.x[g], sum_ct<DV - 1, 2, ORD, T>(xs));
+            if constexpr (DV >= 4) out[3].x[g] = v2c(l.x[g], sum_ct<DV - 1, 3, ORD, T>(xs));
+            if constexpr (DV >= 5) out[4].x[g] = v2c(l.x[g], sum_ct<DV - 1, 4, ORD, T>(xs));
+            if constexpr (DV >= 6) out[5].x[g] = v2c(l.x[g], sum_ct<DV - 1, 5, ORD, T>(xs));
+            if constexpr (DV >= 7) out[6].x[g] = v2c(l.x[g], sum_ct<DV - 1, 6, ORD, T>(xs));
+            if constexpr (DV >= 8) out[7].x[g] = v2c(l.x[g], sum_ct<DV - 1, 7, ORD, T>(xs));
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) lds_store<P>(off[k], out[k]);
@@ -320,11 +361,11 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
         bool store = false;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float xs[DV > 0 ? DV : 1];
+            T xs[DV > 0 ? DV : 1];
 #pragma unroll
             for (int k = 0; k < DV; ++k) xs[k] = x[k].x[g];
-            const float post = l.x[g] + sum_ct<DV, -1, 0, float>(xs);
-            byte |= (post < 0.0f ? 1u : 0u) << g;
+            const T post = l.x[g] + sum_ct<DV, -1, ORD, T>(xs);
+            byte |= (post < (T)0 ? 1u : 0u) << g;
             if ((emask >> g) & 1u) { l.x[g] = post; store = true; }
         }
         if constexpr (MODE == 8) {
@@ -340,12 +381,12 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, float *__restr
     }
 }
 
-template <int G, int MODE>
-__device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__restrict__ llr_s,
+template <int G, int MODE, typename T>
+__device__ __forceinline__ void res_var_dispatch(unsigned char *smem, T *__restrict__ llr_s,
                                                  uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &slo,
-                                                 const uint4 &shi, float a, unsigned emask)
+                                                 const uint4 &shi, T a, unsigned emask)
 {
-#define LDPC_RV(D) case D: res_var_body<G, D, MODE>(smem, llr_s, bits_s, q, slo, shi, a, emask); break;
+#define LDPC_RV(D) case D: res_var_body<G, D, MODE, T>(smem, llr_s, bits_s, q, slo, shi, a, emask); break;
     switch (dv) {
         LDPC_RV(0) LDPC_RV(1) LDPC_RV(2) LDPC_RV(3) LDPC_RV(4) LDPC_RV(5) LDPC_RV(6) LDPC_RV(7) LDPC_RV(8)
     default: break;   // host admits only max_dv <= 8 to this engine
@@ -356,11 +397,11 @@ __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, float *__r
 // Index data (degree, alpha column, the slot offsets) of the NEXT variable of a lane is fetched from
 // global memory (L1/L2 resident, shared by every workgroup) while the current one is processed.
 // (A two-register-set ping-pong that avoids the hand-over copies doubled the code and measured no faster.)
-template <int G, int MODE>
+template <int G, int MODE, typename T>
 __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned char *smem,
-                                              float *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
-                                              const float *__restrict__ alpha_lds,
-                                              const float *__restrict__ alpha_glb, unsigned emask,
+                                              T *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
+                                              const T *__restrict__ alpha_lds,
+                                              const T *__restrict__ alpha_glb, unsigned emask,
                                               int tid, int nt)
 {
     const int n = pl.n;
@@ -384,14 +425,14 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
             if (wide) shin = pl.vslot_hi[qn];
         }
         const int dv = (int)(meta & 0xffu);
-        float a = 0.0f;                                                  // LDS copy of the table when small
+        T a = (T)0;                                                      // LDS copy of the table when small
         if (MODE == 0 || MODE == 4) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
         // one scalar branch into the body of the wave's degree; a class-boundary wave (two or three degrees)
         // goes round once per distinct degree with the other lanes masked off
         for (bool pending = true; pending;) {
             const int dvw = __builtin_amdgcn_readfirstlane(dv);
             if (dv == dvw) {
-                res_var_dispatch<G, MODE>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);
+                res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);
                 pending = false;
             }
         }
@@ -421,10 +462,10 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
 }
 
 // final syndrome of a fixed-T decode from the hard decisions res_var_body<MODE 8> left in the message slots
-template <int G>
+template <int G, typename T>
 __device__ __forceinline__ void res_syndrome_slots(const ResidentPlan &pl, unsigned *sh_unsat, int tid, int nt)
 {
-    constexpr unsigned kSlot = sizeof(Pack<float, G>);
+    constexpr unsigned kSlot = sizeof(Pack<T, G>);
     unsigned acc = 0;
     for (int p = tid; p < pl.m; p += nt) {
         const int dc = pl.dc_s[p];
@@ -458,11 +499,12 @@ __device__ __forceinline__ void res_store_packed(const ResidentArgs &a, long lon
 }
 
 // posterior of the masked codewords sits in llr_s[.][g] (sorted order)
-template <int G>
-__device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentArgs &a, const float *__restrict__ llr_s,
+template <int G, typename T>
+__device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentArgs &a, const T *__restrict__ llr_s,
                                          long long b0, unsigned mask, int iters, unsigned unsat, int tid, int nt)
 {
-    using P = Pack<float, G>;
+    using P = Pack<T, G>;
+    T *posterior = reinterpret_cast<T *>(a.posterior);
     const int n = pl.n;
     if (a.posterior || a.bits || a.packed) {
         for (int j0 = tid; j0 < n; j0 += kEmit * nt) {
@@ -478,9 +520,9 @@ __device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentA
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     if (!((mask >> g) & 1u)) continue;
-                    if (in && a.posterior) a.posterior[(size_t)(b0 + g) * n + j] = p.x[g];
-                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < 0.0f ? 1 : 0;
-                    if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && p.x[g] < 0.0f);
+                    if (in && a.posterior) posterior[(size_t)(b0 + g) * n + j] = p.x[g];
+                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < (T)0 ? 1 : 0;
+                    if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && p.x[g] < (T)0);
                 }
             }
         }
@@ -541,17 +583,25 @@ __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha
 
 // ES: 0 = fixed-iteration kernel, 1 = early-stop kernel (kept apart so that the fixed-T kernel does not carry
 // the posterior/syndrome/emit code of the stop rule: the extra code cost the hot loop ~4 % when merged)
-template <int G, int FORM, bool BPC, int NL, int MS, int ES>
+template <int G, int FORM, bool BPC, int NL, int MS, int ES, typename T = float>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // lds_load/lds_store rely on that (folds away)
-    const int n_alpha_lds = a.alpha_in_lds ? a.T * a.n_alpha : 0;
-    float *llr_s = reinterpret_cast<float *>(res_smem + res_off_llr(pl.S, G));
-    float *alpha_s = reinterpret_cast<float *>(res_smem + res_off_alpha(pl.S, pl.n, G));
-    uint8_t *bits_s = res_smem + res_off_bits(pl.S, pl.n, G, n_alpha_lds);
-    unsigned *sh_unsat = reinterpret_cast<unsigned *>(res_smem + res_off_flag(pl.S, pl.n, G, n_alpha_lds));
-    using P = Pack<float, G>;
+    // T = float: G codewords per workgroup; T = double (fp64 Basic): the same 8-byte slots hold ONE codeword, so the
+    // LDS carve is that of GE = G * sizeof(T) / 4 float codewords.  Table / LLR / posterior pointers of ResidentArgs are
+    // typed float for the common case and re-read as T here.
+    constexpr int GE = G * (int)(sizeof(T) / 4);
+    const int n_alpha_lds = a.alpha_in_lds ? a.T * a.n_alpha * (int)(sizeof(T) / 4) : 0;
+    T *llr_s = reinterpret_cast<T *>(res_smem + res_off_llr(pl.S, GE));
+    T *alpha_s = reinterpret_cast<T *>(res_smem + res_off_alpha(pl.S, pl.n, GE));
+    uint8_t *bits_s = res_smem + res_off_bits(pl.S, pl.n, GE, n_alpha_lds);
+    unsigned *sh_unsat = reinterpret_cast<unsigned *>(res_smem + res_off_flag(pl.S, pl.n, GE, n_alpha_lds));
+    const T *g_llr = reinterpret_cast<const T *>(a.llr);
+    const T *g_beta = reinterpret_cast<const T *>(a.beta);
+    const T *g_alpha = reinterpret_cast<const T *>(a.alpha);
+    const T *g_oms_alpha = reinterpret_cast<const T *>(a.oms_alpha);
+    using P = Pack<T, G>;
     const int tid = threadIdx.x, nt = blockDim.x, n = pl.n;
     const long long b0 = (long long)blockIdx.x * G;
     constexpr unsigned kAll = (1u << G) - 1u;
@@ -573,7 +623,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
                     ip[k] = pl.inv_perm_v[j];
 #pragma unroll
                     for (int g = 0; g < G; ++g)
-                        v[k].x[g] = (b0 + g < a.batch) ? a.llr[(size_t)(b0 + g) * n + j] : 1.0f;
+                        v[k].x[g] = (b0 + g < a.batch) ? g_llr[(size_t)(b0 + g) * n + j] : (T)1;
                 }
             }
 #pragma unroll
@@ -581,7 +631,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
                 if (j0 + k * nt < n) reinterpret_cast<P *>(llr_s)[ip[k]] = v[k];
         }
     }
-    for (int k = tid; k < n_alpha_lds; k += nt) alpha_s[k] = a.alpha[k];
+    for (int k = tid; k < (a.alpha_in_lds ? a.T * a.n_alpha : 0); k += nt) alpha_s[k] = g_alpha[k];
     if (tid == 0) *sh_unsat = 0;
     __syncthreads();
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
@@ -610,7 +660,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
                     P l = L[q];
                     if (a.T == 0) {
 #pragma unroll
-                        for (int g = 0; g < G; ++g) l.x[g] = 0.0f;
+                        for (int g = 0; g < G; ++g) l.x[g] = (T)0;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -621,7 +671,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     }
     // first-round check degree (iteration-invariant) and per-check beta of iteration 0, in registers
     const int dc_pre = tid < pl.m ? pl.dc_s[tid] : 0;
-    float b_pre = (BPC && tid < pl.m && a.T > 0) ? a.beta[pl.bslot_c[tid]] : 0.0f;
+    T b_pre = (BPC && tid < pl.m && a.T > 0) ? g_beta[pl.bslot_c[tid]] : (T)0;
     __syncthreads();
 
     unsigned done = 0;                                   // block-uniform
@@ -630,24 +680,24 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         if (b0 + g >= a.batch) done |= 1u << g;
 
     for (int it = 0; it < a.T; ++it) {
-        const float *beta_row = a.beta + (size_t)it * a.n_beta;
-        const float *oa_row = a.oms_alpha ? a.oms_alpha + (size_t)it * a.n_oms_alpha : nullptr;
+        const T *beta_row = g_beta + (size_t)it * a.n_beta;
+        const T *oa_row = a.oms_alpha ? g_oms_alpha + (size_t)it * a.n_oms_alpha : nullptr;
         const float *thr = FORM == FORM_RCQ ? a.thr + (size_t)a.q_of_iter[it] * a.n_levels : nullptr;
-        const float *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
-        const float *alpha_glb = a.alpha + (size_t)it * a.n_alpha;
+        const T *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
+        const T *alpha_glb = g_alpha + (size_t)it * a.n_alpha;
         if (!LDPC_PROBE(a, 1))
-            res_check_phase<G, FORM, BPC, NL, MS>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, a.rcq_zero0 != 0,
+            res_check_phase<G, FORM, BPC, NL, MS, T>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, a.rcq_zero0 != 0,
                                                   dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
-            b_pre = a.beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
+            b_pre = g_beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
         __syncthreads();
         if (ES && !a.posterior) {
             // reference stop rule without a second gather pass: the variable phase also yields this iteration's
             // hard decisions (the posterior shares the gathered C2V values); outputs are bits only
             const bool last = it == a.T - 1;
-            if (last) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
-            else if (a.unit_alpha) res_var_phase<G, 6>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
-            else res_var_phase<G, 4>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
+            if (last) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
+            else if (a.unit_alpha) res_var_phase<G, 6, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
+            else res_var_phase<G, 4, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
             res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
             __syncthreads();
@@ -664,7 +714,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             continue;
         }
         if (ES) {
-            res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
+            res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
             __syncthreads();
             res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
             __syncthreads();
@@ -673,17 +723,17 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             if (tid == 0) *sh_unsat = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
-                res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, newly, tid, nt);
+                res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, newly, tid, nt);
                 __syncthreads();
-                res_emit<G>(pl, a, llr_s, b0, newly, it + 1, 0u, tid, nt);
+                res_emit<G, T>(pl, a, llr_s, b0, newly, it + 1, 0u, tid, nt);
                 done |= newly;
                 if (done == kAll) return;                // every codeword of the block has its outputs
                 __syncthreads();
             }
         }
         if (it != a.T - 1 && !LDPC_PROBE(a, 2)) {
-            if (a.unit_alpha) res_var_phase<G, 2>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, 0u, tid, nt);
-            else res_var_phase<G, 0>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
+            if (a.unit_alpha) res_var_phase<G, 2, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
+            else res_var_phase<G, 0, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
         }
     }
@@ -696,18 +746,18 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         return;
     }
     if (!LDPC_PROBE(a, 8)) {
-        if (ES) res_var_phase<G, 1>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
-        else res_var_phase<G, 8>(pl, res_smem, llr_s, bits_s, nullptr, nullptr, open, tid, nt);
+        if (ES) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, open, tid, nt);
+        else res_var_phase<G, 8, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, open, tid, nt);
     }
     __syncthreads();
     unsigned unsat = kAll;
     if (!ES && !LDPC_PROBE(a, 8)) {                    // fixed-T mode: success = final syndrome is zero
-        res_syndrome_slots<G>(pl, sh_unsat, tid, nt);
+        res_syndrome_slots<G, T>(pl, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
     }
     if (LDPC_PROBE(a, 4)) return;
-    res_emit<G>(pl, a, llr_s, b0, open, a.T, unsat, tid, nt);
+    res_emit<G, T>(pl, a, llr_s, b0, open, a.T, unsat, tid, nt);
 }
 
 }  // namespace ldpc

@@ -608,3 +608,27 @@ def test_decode_is_capturable_in_a_hip_graph(gpu_device, engine_mode):
         ref = eng.decode(x_new, early_stop=True)
         assert torch.equal(got[0], ref.bits) and torch.equal(got[1], ref.posterior)
         assert torch.equal(got[2], ref.iterations)
+
+
+def test_fp64_basic_runs_on_the_resident_engine_with_identical_results(gpu_device, monkeypatch):
+    """BasicMinSumDecoder with the reference's own float64 LLRs: one fp64 codeword per workgroup in the slots of a
+    float pair; bits / iterations / success equal the golden vectors, posteriors equal the streaming engine's bit for bit"""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    monkeypatch.setenv("LDPC_ENGINE_MODE", "auto")
+    gold = load_golden("ira_basic")
+    code = codes.load_code("ira_1998_1512", max_iterations=int(gold["T"]) if "T" in gold else 10)
+    dec = BasicMinSumDecoder(code, 0.7)
+    eng = dec._engine(torch.float64, gpu_device)
+    assert eng.info()["engine"] == "resident" and eng.info()["codewords_per_workgroup"] == 1
+    llr = torch.from_numpy(np.asarray(gold["llr"], dtype=np.float64)).to(gpu_device)
+    for early in (True, False):
+        eng.set_mode("auto")
+        a = eng.decode(llr, early_stop=early, want_packed=True)
+        eng.set_mode("stream")
+        b = eng.decode(llr, early_stop=early, want_packed=True)
+        assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
+        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)
+        if early:
+            np.testing.assert_array_equal(a.bits.cpu().numpy(), gold["bits"].astype(np.int32))
+            np.testing.assert_array_equal(a.iterations.cpu().numpy(), gold["iters"])
