@@ -106,6 +106,7 @@ namespace {
 int pick_vec(const ldpc_decoder *d, int64_t batch)
 {
     if (batch <= 64) return 1;
+    if (d->schedule == LDPC_SCHED_LAYERED_REF) return 1;   // one dependent chain per wave: as many waves as possible
     return d->dtype == LDPC_F64 ? 2 : 4;
 }
 
@@ -277,7 +278,8 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         if constexpr (sizeof(T) == 4) {
             // posteriors start as the LLRs and are updated in place, check after check, by one wave per tile
             hipLaunchKernelGGL((layered_rcq<VEC>), dim3(w.tiles), dim3(kWave), 0, s, g, (float *)w.llrT, d->thresholds,
-                               d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters);
+                               d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters,
+                               d->g->max_dc);
             HIP_TRY(hipGetLastError());
             if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
             if (bits || posterior)

@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
                                                      const float *__restrict__ thresholds, int n_levels,
                                                      const int *__restrict__ q_of_iter, int T, int early_stop,
                                                      uint64_t *__restrict__ bitsT, uint64_t *__restrict__ done,
-                                                     int *__restrict__ iters)
+                                                     int *__restrict__ iters, int max_dc)
 {
     constexpr int W = kWave * VEC;
     const int lane = threadIdx.x, tile = blockIdx.x;
@@ -741,6 +741,61 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
     for (int it = 0; it < T; ++it) {
         if (early_stop && __ballot(frozen != kAll) == 0ull) break;
         const float *thr = thresholds + (size_t)q_of_iter[it] * n_levels;
+        if constexpr (VEC == 1) {
+            // The walk is ONE dependent chain per wave (a check reads what the previous one wrote), so what counts is
+            // memory round trips per check.  With at most kHeld edges per check: the indices of check i+1 are fetched
+            // while check i is processed, all rows of a check are requested at once and stay in registers for the
+            // update -- one exposed round trip per check instead of index loads, unroll groups and re-reads in series.
+            constexpr int kHeld = 32;
+            if (max_dc <= kHeld) {
+                int var_n[kHeld];
+                int dc_n = 0;
+                auto fetch_idx = [&](int i) {
+                    const int e0n = g.check_ptr[i];
+                    dc_n = g.check_ptr[i + 1] - e0n;
+#pragma unroll
+                    for (int t = 0; t < kHeld; ++t)
+                        if (t < max_dc) var_n[t] = g.var_idx[min(e0n + t, g.E - 1)];      // past the check: unused
+                };
+                if (g.m > 0) fetch_idx(0);
+                for (int i = 0; i < g.m; ++i) {
+                    int var[kHeld];
+                    const int dc = uni(dc_n);
+#pragma unroll
+                    for (int t = 0; t < kHeld; ++t) var[t] = var_n[t];
+                    if (i + 1 < g.m) fetch_idx(i + 1);
+                    float x[kHeld];
+#pragma unroll
+                    for (int t = 0; t < kHeld; ++t)
+                        if (t < dc) x[t] = P[(size_t)var[t] * W];
+                    float m1 = inf_of<float>(), m2 = inf_of<float>();
+                    unsigned par = 0;
+#pragma unroll
+                    for (int t = 0; t < kHeld; ++t)
+                        if (t < dc) {
+                            const float a = __builtin_fabsf(x[t]);
+                            par ^= signbit_of<float>(x[t]);
+                            if (a < m1) { m2 = m1; m1 = a; }
+                            else if (a < m2) { m2 = a; }
+                        }
+                    if (dc == 1) m2 = m1;
+                    if (frozen != kAll) {
+#pragma unroll
+                        for (int t = 0; t < kHeld; ++t)
+                            if (t < dc) {
+                                const float a = __builtin_fabsf(x[t]);
+                                const float raw = (a == m1) ? m2 : m1;     // arg-min edge; ties make min2 == min1
+                                const float w = flip_sign<float>(raw, par ^ signbit_of<float>(x[t]));
+                                const float mag = __builtin_fabsf(w);
+                                float rec = thr[0];
+                                for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                                P[(size_t)var[t] * W] = x[t] + flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
+                            }
+                    }
+                }
+                goto checks_done;
+            }
+        }
         for (int i = 0; i < g.m; ++i) {
             const int e0 = uni(g.check_ptr[i]);
             const int dc = uni(g.check_ptr[i + 1]) - e0;
@@ -782,6 +837,7 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
                 if (frozen != kAll) st<float, VEC>(row, v);
             }
         }
+    checks_done:
         if (early_stop) {
             const unsigned newly = ~syndrome() & ~frozen & kAll;
 #pragma unroll
