@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
 
 
+@pytest.fixture(autouse=True)
+def inference_mode():
+    """These are decode (inference) tests: with autograd enabled the trainable decoders keep their messages for
+    backward and run the saving streaming path, which tests/test_gpu_training.py covers.  Here grad is off so that
+    LDPC_ENGINE_MODE really selects the engine under test; check_neural re-enables it for one comparison."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(autouse=True, params=["auto", "stream"])
 def engine_mode(request, monkeypatch):
     """both engines: 'auto' = LDS-resident fused kernel where the code qualifies, 'stream' = HBM sweeps"""

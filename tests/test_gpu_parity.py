@@ -19,6 +19,15 @@ QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
 POST_TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def inference_mode():
+    """These are decode (inference) tests: with autograd enabled the trainable decoders keep their messages for
+    backward and run the saving streaming path, which tests/test_gpu_training.py covers.  Here grad is off so that
+    LDPC_ENGINE_MODE really selects the engine under test; check_neural re-enables it for one comparison."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(autouse=True, params=["auto", "stream"])
 def engine_mode(request, monkeypatch):
     """every test runs on both engines: 'auto' picks the LDS-resident fused kernel for codes that
@@ -70,8 +79,11 @@ def check_neural(dec, sub, gpu):
     assert bits.dtype == torch.int32 and post.dtype == torch.float32 and iters.dtype == torch.int32
     if any(p.requires_grad for p in dec.parameters()):
         # grad enabled (the reference's default call): same numbers; the normalised min-sum decoders attach a grad_fn
-        b2, p2, i2 = dec(llr.to(gpu))
+        with torch.enable_grad():
+            b2, p2, i2 = dec(llr.to(gpu))
         assert torch.equal(b2, bits) and torch.equal(i2, iters) and torch.equal(p2.detach(), post)
+        assert p2.requires_grad == (type(dec).__name__ in ("Neural2DMinSumDecoder", "Neural2DOffsetMinSumDecoder",
+                                                           "NeuralMinSumDecoder", "NeuralOffsetMinSumDecoder"))
     np.testing.assert_array_equal(iters.detach().cpu().numpy(), sub["iters"])
     np.testing.assert_array_equal(bits.detach().cpu().numpy(), sub["bits"].astype(np.int32))
     assert_post(post.detach().cpu().numpy(), sub["posterior"])
