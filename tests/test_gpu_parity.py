@@ -644,3 +644,89 @@ def test_fp64_basic_runs_on_the_resident_engine_with_identical_results(gpu_devic
         if early:
             np.testing.assert_array_equal(a.bits.cpu().numpy(), gold["bits"].astype(np.int32))
             np.testing.assert_array_equal(a.iterations.cpu().numpy(), gold["iters"])
+
+
+def _random_code(rng, T):
+    """random sparse graph the resident engine accepts: check degrees 1..20, variable degrees <= 8, now and then a
+    degree-0 check or variable"""
+    from ldpc_decoder import LDPCCode
+    m = int(rng.integers(4, 60))
+    n = int(rng.integers(m + 3, 160))
+    H = np.zeros((m, n), dtype=np.int64)
+    room = np.full(n, 8)
+    for i in range(m):
+        dc = int(rng.integers(0 if rng.random() < 0.05 else 1, min(20, n) + 1))
+        cand = np.flatnonzero(room > 0)
+        pick = rng.choice(cand, size=min(dc, len(cand)), replace=False)
+        H[i, pick] = 1
+        room[pick] -= 1
+    return LDPCCode(n=n, k=max(n - m, 1), H=H, max_iterations=T)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_graphs_engines_agree_with_the_oracle(seed, gpu_device, oracle_mod):
+    """property test over random Tanner graphs: for every decoder form the resident engine, the streaming engine and the
+    CPU oracle give the same bits / iterations / success (and the two engines bit-identical posteriors)"""
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
+    from rcq_decoder import WeightedRCQDecoder
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(1, 7))
+    code = _random_code(rng, T)
+    og = oracle_mod.OracleGraph(code.H)
+    B = int(rng.integers(1, 150))
+    llr = (rng.standard_normal((B, code.n)) * 2.5 + 1.0).astype(np.float32)
+    llr[rng.random(llr.shape) < 0.01] = 0.0                     # exact zeros
+    if B > 3:
+        llr[1] = np.round(llr[1])                               # ties
+        llr[2] = np.abs(llr[2]) + 3.0                           # stops at once
+    x = torch.from_numpy(llr).to(gpu_device)
+    early = bool(seed % 2 == 0)
+
+    def both_engines(eng, inp):
+        eng.set_mode("auto")
+        assert eng.info()["engine"] == "resident"
+        a = eng.decode(inp, early_stop=early, want_packed=True)
+        eng.set_mode("stream")
+        b = eng.decode(inp, early_stop=early, want_packed=True)
+        assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
+        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)
+        return a
+
+    wtype = int(rng.integers(1, 5))
+    dec = Neural2DMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=T)
+    beta, alpha = rand_weights(dec, rng)
+    a = both_engines(dec._get_engine(gpu_device), x)
+    ob, op, oi, osucc = oracle_mod.neural2d(og, llr, wtype, T, beta, alpha, early_stop=early)
+    np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+    np.testing.assert_array_equal(a.success.cpu().numpy(), osucc)
+    assert_post(a.posterior.cpu().numpy(), op)
+
+    w = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=2, max_iterations=T)
+    beta, alpha = rand_weights(w, rng)
+    a = both_engines(w._get_engine(gpu_device), x)
+    ob, op, oi, osucc = oracle_mod.weighted_rcq(og, llr, 3, QP, 2, T, beta, alpha, early_stop=early)
+    np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+    np.testing.assert_array_equal(a.posterior.cpu().numpy(), op)
+
+    o = Neural2DOffsetMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+    with torch.no_grad():
+        for p in o.beta_weights.values():
+            p.fill_(float(np.float32(rng.uniform(0.0, 0.6))))
+        for p in o.alpha_weights.values():
+            p.fill_(float(np.float32(rng.uniform(0.0, 0.3))))
+    a = both_engines(o._get_engine(gpu_device), x)
+    ob, op, oi, _ = oracle_mod.neural2d_offset(og, llr, 2, T, {k: float(v.item()) for k, v in o.beta_weights.items()},
+                                               {k: float(v.item()) for k, v in o.alpha_weights.items()}, early_stop=early)
+    np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+
+    basic = BasicMinSumDecoder(code, 0.7)                       # the reference's float64 decoder, resident fp64 kernel
+    x64 = torch.from_numpy(llr.astype(np.float64)).to(gpu_device)
+    a = both_engines(basic._engine(torch.float64, gpu_device), x64)
+    ob, op, oi, osucc = oracle_mod.basic_minsum(og, llr.astype(np.float64), 0.7, T, early_stop=early)
+    np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+    np.testing.assert_array_equal(a.success.cpu().numpy(), osucc)
