@@ -3,7 +3,7 @@
 # PMC passes (separate runs for FETCH_SIZE / WRITE_SIZE).  Outputs under gpurun_out/.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/round5; mkdir -p $O
+O=gpurun_out/round6; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest_fullsize.log 2>&1; echo "pytest rc=$?" >> $O/pytest_fullsize.log
 for w in basic neural2d rcq wrcq_dvbs2; do
   timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 3 > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed" >> $O/errors.log
