@@ -104,23 +104,39 @@ class SharingLayout:
             self.alpha_suffix = [None]
             self.alpha_edge_slot = np.zeros(graph.E, dtype=np.int32)
 
-    @staticmethod
-    def _table(params, suffixes, T: int, default: float) -> np.ndarray:
+    def _table(self, params, suffixes, T: int, default: float) -> np.ndarray:
+        """[max(T,1), len(suffixes)] float32.  WHICH parameter feeds which cell is resolved once per parameter set
+        (the key lookups dominate a one-codeword call otherwise); the VALUES are re-read on every call, so in-place
+        updates of any kind (optimizer, fill_, .data) are always seen."""
         rows = max(T, 1)
         out = np.full((rows, len(suffixes)), default, dtype=np.float32)
-        picks, where = [], []
-        for t in range(T):
-            for s, suf in enumerate(suffixes):
-                if suf is None:
-                    continue
-                key = f"iter_{t}_{suf}"
-                if key in params:               # reference: ParameterDict.get(key, default)
-                    picks.append(params[key].detach().reshape(-1)[:1])
-                    where.append((t, s))
+        ids = tuple(map(id, params.values()))
+        cache = self.__dict__.setdefault("_cells", {})
+        key = (id(params), tuple(suffixes), T)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ids:
+            picks, tt, ss = [], [], []
+            for t in range(T):
+                for s, suf in enumerate(suffixes):
+                    if suf is None:
+                        continue
+                    k = f"iter_{t}_{suf}"
+                    if k in params:               # reference: ParameterDict.get(key, default)
+                        picks.append(params[k])
+                        tt.append(t)
+                        ss.append(s)
+            hit = (ids, picks, np.asarray(tt, dtype=np.intp), np.asarray(ss, dtype=np.intp))
+            cache[key] = hit
+        _, picks, tt, ss = hit
         if picks:
-            vals = torch.cat(picks).to(dtype=torch.float32, device="cpu").numpy()
-            tt, ss = zip(*where)
-            out[list(tt), list(ss)] = vals
+            with torch.no_grad():
+                try:                                          # the usual case: every parameter has shape [1]
+                    flat = torch.cat(picks)
+                    if flat.numel() != len(picks):
+                        raise RuntimeError("parameter with more than one element")
+                except RuntimeError:
+                    flat = torch.cat([p.reshape(-1)[:1] for p in picks])
+                out[tt, ss] = flat.to(dtype=torch.float32, device="cpu").numpy()
         return out
 
     @staticmethod
