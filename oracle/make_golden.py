@@ -700,6 +700,14 @@ def gen_grad(which):
                 out[f"o{wtype}_T4_{k}"] = v
         for k, v in run_grad_edge_offset(code, H, llrs, 4, seed=78).items():
             out[f"edgeoff_{k}"] = v
+    elif which == "ira":
+        H = load_edge_list("ira_1998_1512")
+        code = CachedCode(n=1998, k=1512, H=H, max_iterations=10)
+        llrs = np.concatenate([awgn_llr_decoder_convention(rng, 1, 1998, 2.0, np.float32),
+                               awgn_llr_decoder_convention(rng, 1, 1998, 5.5, np.float32)])
+        out = {"graph": np.asarray("ira_1998_1512")}
+        for k, v in run_grad_neural2d(code, H, llrs, 2, 3, rng).items():
+            out[f"t2_T3_{k}"] = v
     else:
         H = load_edge_list("small_96_48")
         code = CachedCode(n=96, k=48, H=H, max_iterations=10)
@@ -732,6 +740,7 @@ SETS = {
     "layered_rcq": gen_layered,
     "grad_toy": lambda: gen_grad("toy"),
     "grad_small": lambda: gen_grad("small"),
+    "grad_ira": lambda: gen_grad("ira"),
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 

@@ -85,9 +85,10 @@ def test_golden_toy_single_vector_calls_accumulate(gpu_device):
     check_neural2d_block(gold, golden_sub(gold, "t2_T6"), gpu_device, batched=False)
 
 
-@pytest.mark.parametrize("tag", ["t2_T4", "t1_T3"])
-def test_golden_small_neural2d_gradients(gpu_device, tag):
-    gold = load_golden("grad_small")
+@pytest.mark.parametrize("name,tag", [("grad_small", "t2_T4"), ("grad_small", "t1_T3"), ("grad_ira", "t2_T3")])
+def test_golden_small_and_ira_neural2d_gradients(gpu_device, name, tag):
+    """96x48 code and the (1998,1512) benchmark code: gradients of the real reference under autograd"""
+    gold = load_golden(name)
     check_neural2d_block(gold, golden_sub(gold, tag), gpu_device)
 
 

@@ -19,7 +19,7 @@ def _graph(gold, oracle_mod):
 
 
 @pytest.mark.parametrize("name,tags", [("grad_toy", [f"t{w}_T{T}" for w in (1, 2, 3, 4) for T in (3, 6)]),
-                                       ("grad_small", ["t2_T4", "t1_T3"])])
+                                       ("grad_small", ["t2_T4", "t1_T3"]), ("grad_ira", ["t2_T3"])])
 def test_gradient_oracle_equals_reference_autograd(name, tags, oracle_mod):
     import grad_oracle
     gold = load_golden(name)
