@@ -97,6 +97,23 @@ def make_llr(batch, n, snr_db, seed, device):
     return (2.0 * (1.0 + (s2 ** 0.5) * z) / s2).contiguous()
 
 
+def resident_lds_model(g, T, B, G, ms):
+    """What bounds the fused kernel itself: LDS traffic of its phases against the LDS rates of MI355X_MICROARCH.md
+    ("LDS": ds_read_b64 256 B/clk/CU, ds_write_b64 ~85 B/clk/CU, 256 CUs at 2.4 GHz), conflict-free.  Slots are
+    4*G bytes; per codeword group and iteration the check phase reads every slot twice and writes it once, the
+    variable phase reads every slot and its LLR once and writes every slot once."""
+    slot = 4 * G
+    groups = (B + G - 1) // G
+    reads = groups * slot * (T * 2 * g.E + T * (g.E + g.n))          # bytes
+    writes = groups * slot * (T * g.E + T * g.E)
+    rd_peak, wr_peak = 256 * 256 * 2.4e9, 85 * 256 * 2.4e9             # B/s, all CUs
+    t_min = reads / rd_peak + writes / wr_peak
+    return {"bound": "lds", "lds_read_bytes": reads, "lds_write_bytes": writes, "lds_min_ms": t_min * 1e3,
+            "frac": t_min * 1e3 / ms,
+            "note": "conflict-free LDS time of the iteration phases / measured kernel time; the variable phase's gathers "
+                    "and scatters take ~2 LDS passes per instruction, the rest is VALU issue and barriers"}
+
+
 def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
     """The CPU oracle (oracle/ldpc_oracle.c, a C port of the reference's loops; the Python
     reference itself cannot travel to the GPU box) on a bounded sample of the same workload."""
@@ -323,6 +340,7 @@ def main():
                                "traffic": traffic_db.get("resident_decode_bytes_per_launch"),
                                "measured_copy_GBps": copy_gbs,
                                "algorithmic_bytes_per_launch": per_cw_decode * B, "ms_per_launch": ms,
+                               "own_limiter": resident_lds_model(g, T, B, eng.info()["codewords_per_workgroup"], ms),
                                "note": "algorithmic bytes = T(16E+4n)+8n per codeword (10E for RCQ) of the HBM-streaming "
                                        "formulation; the fused kernel keeps messages in LDS, so frac > 1 means it beats "
                                        "the HBM roofline of that formulation; its own limiter is LDS/instruction issue"}
