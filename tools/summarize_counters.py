@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""gpurun_out/counters/p*/ (tools/resident_counters.sh) -> profiles/<tag>_resident_counters.csv: per-launch averages of the
+SQ / LDS counters of ldpc::resident_decode plus a few derived ratios."""
+import collections, csv, glob, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "counters", "p*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "resident_decode" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in agg.items()}
+d = dict(avg)
+if "SQ_WAVE_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
+    d["derived_valu_active_per_wave_cycle"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"]
+if "SQ_BUSY_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
+    d["derived_valu_active_per_busy_cycle"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_BUSY_CYCLES"]
+if "SQ_LDS_IDX_ACTIVE" in avg and "SQ_LDS_BANK_CONFLICT" in avg:
+    d["derived_lds_conflict_share_of_lds_cycles"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
+if "SQ_WAIT_ANY" in avg and "SQ_WAVE_CYCLES" in avg:
+    d["derived_wait_share_of_wave_cycles"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
+out = os.path.join(ROOT, "profiles", f"{tag}_resident_counters.csv")
+with open(out, "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["counter", "average_per_launch"])
+    for k in sorted(d):
+        w.writerow([k, d[k]])
+print(open(out).read())
