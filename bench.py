@@ -163,9 +163,17 @@ def main():
     ap.add_argument("--sweep-reps", type=int, default=20)
     ap.add_argument("--no-overlap", action="store_true", help="join every step's all-gather before the next decode")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the all-gather path even with one rank (checks the RCCL plumbing on a single GPU)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch (default: the workload's) is the TOTAL over all GPUs, split evenly")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON result: libraries that print there (RCCL writes a five-line version
+    # banner to stdout when its first communicator comes up) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,8 +186,12 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; gloo = 1-GPU rehearsal
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
@@ -204,9 +216,9 @@ def main():
     def step():
         """decode this rank's shard, then all-gather the bit-packed hard decisions.  The gather of step k
         runs on RCCL's stream while step k+1 decodes (separate buffers), and is joined one step later."""
-        res = eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post, want_packed=world > 1)
+        res = eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post, want_packed=use_dist)
         gathered = None
-        if world > 1:
+        if use_dist:
             if backend != "nccl":                                  # rehearsal path: host-side gather
                 gathered = all_gather_hard_decisions(res.packed_bits.cpu(), B * world)
             elif args.no_overlap:
@@ -222,7 +234,7 @@ def main():
     def fence():
         while pending:
             pending.pop()[0].wait()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -234,7 +246,7 @@ def main():
         res, gathered = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -366,8 +378,11 @@ def main():
         out["decode_algorithmic_GBps"] = per_cw_decode * B / (ms_per_step * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
