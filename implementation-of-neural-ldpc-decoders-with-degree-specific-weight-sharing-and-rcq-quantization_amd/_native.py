@@ -126,7 +126,7 @@ def load():
         lib.ldpc_decode_saving.restype = C.c_int
         lib.ldpc_decode_saving.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]
         lib.ldpc_backward.restype = C.c_int
-        lib.ldpc_backward.argtypes = [vp, vp, C.c_size_t, vp, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.ldpc_backward.argtypes = [vp, vp, C.c_size_t, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         lib.ldpc_last_error.restype = C.c_char_p
         lib.ldpc_last_error.argtypes = []
         lib.ldpc_abi_version.restype = C.c_int

@@ -30,8 +30,12 @@ _warned = False
 RECYCLE_SAVED = True        # release the saved messages to the engine's spare slot after backward (see backward())
 
 
-def wants_grad(module: torch.nn.Module) -> bool:
-    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+def wants_grad(module: torch.nn.Module, llr=None) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    if isinstance(llr, torch.Tensor) and llr.requires_grad:
+        return True
+    return any(p.requires_grad for p in module.parameters())
 
 
 def saved_state_fits(engine, batch: int) -> bool:
@@ -54,7 +58,12 @@ class MinSumDecodeFn(torch.autograd.Function):
     otherwise the variable-side multiplier (engine slot alpha)."""
 
     @staticmethod
-    def forward(ctx, beta_table, alpha_table, engine, xd, early_stop, alpha_is_oms=False):
+    def forward(ctx, beta_table, alpha_table, engine, xd, early_stop, alpha_is_oms=False, llr_in=None):
+        """xd: the LLRs as the engine takes them (detached, fp32, on the GPU); llr_in: the caller's own tensor when it
+        requires grad (a trainable front end feeding the decoder) -- its gradient is d loss/d llr from the same sweep"""
+        ctx.llr_meta = None
+        if llr_in is not None and llr_in.requires_grad:
+            ctx.llr_meta = (llr_in.device, llr_in.dtype, tuple(llr_in.shape))
         res, saved = engine.decode_saving(xd, early_stop=early_stop)
         ctx.engine, ctx.saved, ctx.xd, ctx.iters = engine, saved, xd, res.iterations
         ctx.alpha_is_oms = bool(alpha_is_oms)
@@ -82,8 +91,12 @@ class MinSumDecodeFn(torch.autograd.Function):
         same = np.array_equal(held[0], ctx.tables[0]) and (held_alpha is None or np.array_equal(held_alpha, ctx.tables[1]))
         if not same:                       # the weights moved on since this forward: put its tables back for the sweep
             MinSumDecodeFn._upload(eng, ctx.tables[0], ctx.tables[1], ctx.alpha_is_oms)
+        gl = None
         try:
-            gb, ga, goa = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post)
+            if ctx.llr_meta is not None:
+                gb, ga, goa, gl = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post, want_grad_llr=True)
+            else:
+                gb, ga, goa = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post)
         finally:
             if not same:
                 MinSumDecodeFn._upload(eng, held[0], held_alpha, ctx.alpha_is_oms)
@@ -93,7 +106,10 @@ class MinSumDecodeFn(torch.autograd.Function):
         if ctx.alpha_is_oms:
             ga = goa if goa is not None else torch.zeros(ctx.tables[1].shape, dtype=torch.float32, device=gb.device)
         bdev, bdt, adev, adt = ctx.meta
-        return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None, None
+        if gl is not None:
+            ldev, ldt, lshape = ctx.llr_meta
+            gl = gl.to(device=ldev, dtype=ldt).reshape(lshape)
+        return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None, None, gl
 
 
 def table_from_params(params, where, shape, default: float) -> torch.Tensor:

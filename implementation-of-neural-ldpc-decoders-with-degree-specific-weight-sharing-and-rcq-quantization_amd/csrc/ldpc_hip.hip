@@ -958,6 +958,7 @@ struct BackwardWs {
     int vec = 0, tiles = 0;
     float *llrT = nullptr, *gpostT = nullptr, *gv2c = nullptr, *gc2v = nullptr, *gbeta = nullptr, *galpha = nullptr;
     float *goa = nullptr;             // offset form: per-edge partials of the check-side alpha
+    float *gllrT = nullptr;           // accumulator of d loss/d llr (starts as a copy of gpostT)
     size_t part_bytes = 0, total = 0;
 };
 BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
@@ -973,12 +974,14 @@ BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
     const size_t o_gb = take(T * w.tiles * E * 4), o_ga = take(T * w.tiles * n * 4);
     const size_t o_goa = take(d->form == LDPC_C2V_OMS ? T * w.tiles * E * 4 : 0);
     w.part_bytes = off - o_gb;
+    const size_t o_gl = take(tw * n * 4);
     w.total = off;
     if (base) {
         char *b = (char *)base;
         w.llrT = (float *)(b + o_llr); w.gpostT = (float *)(b + o_gp); w.gv2c = (float *)(b + o_gv);
         w.gc2v = (float *)(b + o_gc); w.gbeta = (float *)(b + o_gb); w.galpha = (float *)(b + o_ga);
         w.goa = (float *)(b + o_goa);
+        w.gllrT = (float *)(b + o_gl);
     }
     return w;
 }
@@ -986,7 +989,7 @@ BackwardWs carve_backward(const ldpc_decoder *d, int64_t batch, void *base)
 template <int VEC>
 int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, int64_t batch, const int32_t *iterations,
                   const float *grad_posterior, float *grad_beta, float *grad_alpha, float *grad_oms_alpha,
-                  const BackwardWs &w, hipStream_t s)
+                  float *grad_llr, const BackwardWs &w, hipStream_t s)
 {
     constexpr int W = 64 * VEC;
     constexpr int JT = 32;
@@ -997,6 +1000,8 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, llr, w.llrT, (long long)batch, g.n, vc);
     hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, grad_posterior, w.gpostT, (long long)batch, g.n, vc);
     HIP_TRY(hipMemsetAsync(w.gbeta, 0, w.part_bytes, s));
+    if (grad_llr)
+        HIP_TRY(hipMemcpyAsync(w.gllrT, w.gpostT, (size_t)w.tiles * W * g.n * sizeof(float), hipMemcpyDeviceToDevice, s));
     const int cb = (g.m + kWavesPerBlock - 1) / kWavesPerBlock, vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 cgrid((unsigned)((size_t)w.tiles * cb)), vgrid((unsigned)((size_t)w.tiles * vb));
     const size_t epart = (size_t)w.tiles * g.E, vpart = (size_t)w.tiles * g.n;
@@ -1009,8 +1014,9 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     hipLaunchKernelGGL((cn_backward<VEC, FIRST_, FORM_>), cgrid, blk, 0, s, g, (const float *)(SRC_),                  \
                        (const float *)w.gc2v, (const float *)w.gpostT, iterations, (long long)batch, t, beta_row,     \
                        (const int *)d->beta_slot, (float *)(OUT_), w.gbeta + (size_t)t * epart, goa, cb)
+        float *gv0 = grad_llr ? w.gv2c : nullptr;        // d loss/d v2c_0 is needed only for the input gradient
         if (t == 0) {
-            if (oms) LDPC_CNB(true, FORM_OMS, w.llrT, nullptr); else LDPC_CNB(true, FORM_NMS, w.llrT, nullptr);
+            if (oms) LDPC_CNB(true, FORM_OMS, w.llrT, gv0); else LDPC_CNB(true, FORM_NMS, w.llrT, gv0);
         } else {
             if (oms) LDPC_CNB(false, FORM_OMS, saved + sl.v2c_off(t), w.gv2c);
             else LDPC_CNB(false, FORM_NMS, saved + sl.v2c_off(t), w.gv2c);
@@ -1019,9 +1025,13 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
                                (const float *)w.gv2c, iterations, (long long)batch, t, alpha_row, (const int *)d->alpha_slot,
                                w.gc2v, w.galpha + (size_t)(t - 1) * vpart, vb);
         }
+        if (grad_llr)                                     // g_llr += sum over the edges of every variable of g_v2c_t
+            hipLaunchKernelGGL((llr_backward_accumulate<VEC>), vgrid, blk, 0, s, g, (const float *)w.gv2c, w.gllrT, vb);
 #undef LDPC_CNB
     }
     HIP_TRY(hipGetLastError());
+    if (grad_llr)
+        hipLaunchKernelGGL((untranspose_rows<VEC>), tgrid, blk, 0, s, (const float *)w.gllrT, grad_llr, (long long)batch, g.n, vc);
     if (grad_beta) {
         HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)T * d->n_beta * 4, s));
         hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
@@ -1079,11 +1089,11 @@ int ldpc_decode_saving(const ldpc_decoder *d, const void *llr, int64_t batch, in
 
 int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, const void *llr, int64_t batch,
                   const int32_t *iterations, const void *grad_posterior, void *grad_beta, void *grad_alpha,
-                  void *grad_oms_alpha, void *workspace, size_t workspace_bytes, void *stream)
+                  void *grad_oms_alpha, void *grad_llr, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = train_supported(d)) return rc;
     if (batch < 0) return fail(LDPC_ERR_ARG, "batch < 0");
-    if (!grad_beta && !grad_alpha && !grad_oms_alpha) return LDPC_OK;
+    if (!grad_beta && !grad_alpha && !grad_oms_alpha && !grad_llr) return LDPC_OK;
     DeviceGuard guard(d->g->device);
     hipStream_t s = (hipStream_t)stream;
     if (batch == 0 || d->g->n == 0 || d->T == 0 || d->g->E == 0) {       // no iteration ran: the posterior is the LLR
@@ -1091,6 +1101,10 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
         if (grad_alpha) HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)std::max(d->T, 1) * d->n_alpha * 4, s));
         if (grad_oms_alpha && d->n_oms_alpha > 0)
             HIP_TRY(hipMemsetAsync(grad_oms_alpha, 0, (size_t)std::max(d->T, 1) * d->n_oms_alpha * 4, s));
+        if (grad_llr && batch > 0 && d->g->n > 0) {              // no iteration ran: posterior == llr
+            if (!grad_posterior) return fail(LDPC_ERR_ARG, "NULL grad_posterior");
+            HIP_TRY(hipMemcpyAsync(grad_llr, grad_posterior, (size_t)batch * d->g->n * 4, hipMemcpyDeviceToDevice, s));
+        }
         return LDPC_OK;
     }
     if (!saved || !llr || !iterations || !grad_posterior || !workspace) return fail(LDPC_ERR_ARG, "NULL argument");
@@ -1102,9 +1116,9 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
     if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
     if (w.vec == 1)
         return backward_impl<1>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
-                                (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, w, s);
+                                (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, (float *)grad_llr, w, s);
     return backward_impl<4>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
-                            (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, w, s);
+                            (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, (float *)grad_llr, w, s);
 }
 
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])

@@ -82,13 +82,13 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
 
     const size_t lane_off = (size_t)lane * VEC;
     const size_t erow = ((size_t)tile * g.E + e0) * W + lane_off;
-    float *out_base = FIRST ? nullptr : gv2c_out + erow;
+    float *out_base = gv2c_out ? gv2c_out + erow : nullptr;      // FIRST: only when d loss/d llr is wanted
     if (!any) {                                   // nothing of this wave is live: the consumers still read zeros
         Pack<float, VEC> z;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) z.x[c] = 0.0f;
         for (int u = 0; u < dc; ++u) {
-            if (!FIRST) st<float, VEC>(out_base + (size_t)u * W, z);
+            if (out_base) st<float, VEC>(out_base + (size_t)u * W, z);
             if (lane == 0) {
                 gbeta_part[(size_t)tile * g.E + e0 + u] = 0.0f;
                 if (FORM == FORM_OMS && goa_part) goa_part[(size_t)tile * g.E + e0 + u] = 0.0f;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
             if (FORM == FORM_OMS && goa_part) goa_part[(size_t)tile * g.E + e0 + u] = goa;
         }
     }
-    if (FIRST) return;
+    if (!out_base) return;
     for (int u = 0; u < dc; ++u) {
         Pack<float, VEC> re, o;
 #pragma unroll
@@ -299,6 +299,56 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     }
     ga = wave_sum(ga);
     if (lane == 0) galpha_part[(size_t)tile * g.n + j] = ga;
+}
+
+// d loss/d llr: the LLR of variable j enters the returned posterior directly and every v2c message of j
+// (v2c_0 = llr, v2c_t = llr + alpha * sum(...)), so  g_llr[j] = g_post[j] + sum over iterations and edges of g_v2c.
+// One wave = one variable x W codewords; called once per backward step with that step's g_v2c rows (zero for
+// codewords that take no part), accumulating in place in gllrT [tile][n][W] (initialised with g_post).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void llr_backward_accumulate(GraphDev g, const float *__restrict__ gv2c,
+                                                                  float *__restrict__ gllrT, int var_blocks)
+{
+    constexpr int W = kWave * VEC;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int j = uni((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
+    if (j >= g.n) return;
+    const int k0 = uni(g.var_ptr[j]);
+    const int dv = uni(g.var_ptr[j + 1]) - k0;
+    if (dv == 0) return;
+    const size_t base = (size_t)tile * g.E * W + (size_t)lane * VEC;
+    float *acc_row = gllrT + ((size_t)tile * g.n + j) * W + (size_t)lane * VEC;
+    Pack<float, VEC> acc = ld<float, VEC>(acc_row);
+#pragma unroll 4
+    for (int k = 0; k < dv; ++k) {
+        const Pack<float, VEC> gv = ld<float, VEC>(gv2c + base + (size_t)g.csc_edge[k0 + k] * W);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc.x[c] += gv.x[c];
+    }
+    st<float, VEC>(acc_row, acc);
+}
+
+// [tile][n][W] -> [batch][n] (rows of padding codewords are dropped)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void untranspose_rows(const float *__restrict__ srcT, float *__restrict__ dst,
+                                                           long long batch, int n, int var_chunks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int JT = 32;
+    __shared__ float s[JT][W + 1];
+    const int tile = blockIdx.x / var_chunks;
+    const int j0 = (blockIdx.x % var_chunks) * JT;
+    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+        const int jj = idx / W, w = idx % W;
+        if (j0 + jj < n) s[jj][w] = srcT[((size_t)tile * n + j0 + jj) * W + w];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+        const int r = idx / JT, jj = idx % JT;
+        const long long b = (long long)tile * W + r;
+        if (b < batch && j0 + jj < n) dst[(size_t)b * n + j0 + jj] = s[jj][r];
+    }
 }
 
 // grad_table[t][slot(x)] += sum over tiles of part[t][tile][x]   (x = edge for beta, variable for alpha);

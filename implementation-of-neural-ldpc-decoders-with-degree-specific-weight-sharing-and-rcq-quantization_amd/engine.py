@@ -285,10 +285,11 @@ class DecodeEngine:
                                                        C.c_void_p(stream)), "ldpc_decode_saving")
         return DecodeResult(bits, post, iters, succ.bool(), None), saved
 
-    def backward(self, saved: torch.Tensor, llr: torch.Tensor, iterations: torch.Tensor, grad_posterior: torch.Tensor):
+    def backward(self, saved: torch.Tensor, llr: torch.Tensor, iterations: torch.Tensor, grad_posterior: torch.Tensor,
+                 want_grad_llr: bool = False):
         """(d loss/d beta [T, beta slots], d loss/d alpha [T, alpha slots], d loss/d oms_alpha [T, slots] | None)
         for a loss with d loss/d posterior = grad_posterior [B, n]; `saved`, `iterations` from decode_saving of the
-        same llr with the same weight tables."""
+        same llr with the same weight tables.  want_grad_llr: also return d loss/d llr [B, n]."""
         llr = self._check_llr(llr)
         B, n = llr.shape
         dev = self.device
@@ -301,14 +302,17 @@ class DecodeEngine:
         gb = torch.zeros(self._table_shapes[0], dtype=torch.float32, device=dev)
         ga = torch.zeros(self._table_shapes[1], dtype=torch.float32, device=dev)
         goa = None if self._table_shapes[2] is None else torch.zeros(self._table_shapes[2], dtype=torch.float32, device=dev)
+        gl = torch.zeros((B, n), dtype=torch.float32, device=dev) if want_grad_llr else None
         if B > 0:
             ws = self._train_workspace(B)
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
                 nat.check(self._lib.ldpc_backward(self.handle, p(saved), saved.numel(), p(llr), B, p(iterations), p(gp),
-                                                  p(gb), p(ga), p(goa), p(ws), ws.numel(), C.c_void_p(stream)),
+                                                  p(gb), p(ga), p(goa), p(gl), p(ws), ws.numel(), C.c_void_p(stream)),
                           "ldpc_backward")
+        if want_grad_llr:
+            return gb, ga, goa, gl
         return gb, ga, goa
 
     def debug_sweep(self, batch: int, which: int, it: int):

@@ -125,7 +125,8 @@ class _DegreeSharedDecoder(nn.Module):
         bt, at = self._sharing_layout().tables_torch(self.beta_weights, self.alpha_weights, int(self.max_iterations),
                                                      self._beta_default, self._alpha_default)
         xd = x.detach().to(device=eng.device, dtype=torch.float32)
-        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop), self._alpha_is_oms)
+        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop), self._alpha_is_oms,
+                                                    x if x.requires_grad else None)
         out_dev = llr.device
         if single:
             return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
@@ -163,7 +164,7 @@ class Neural2DMinSumDecoder(_DegreeSharedDecoder):
             decoded_bits (int32), posterior (float32), iterations (int, or int32[B])
         """
         import autograd_bridge as ab
-        if ab.wants_grad(self):
+        if ab.wants_grad(self, llr):
             out = self._decode_with_grad(llr, early_stop, device)
             if out is not None:
                 return out
@@ -202,7 +203,7 @@ class Neural2DOffsetMinSumDecoder(_DegreeSharedDecoder):
 
     def forward(self, llr: torch.Tensor, early_stop: bool = True, device=None):
         import autograd_bridge as ab
-        if ab.wants_grad(self):            # relu / offset are differentiable in the reference too (:396-401)
+        if ab.wants_grad(self, llr):       # relu / offset are differentiable in the reference too (:396-401)
             out = self._decode_with_grad(llr, early_stop, device)
             if out is not None:
                 return out

@@ -100,7 +100,7 @@ class _EdgeWeightDecoder(nn.Module):
         eng = self._get_engine(x.device if x.is_cuda else device)
         out_dev = llr.device
         import autograd_bridge as ab
-        if ab.wants_grad(self) and ab.saved_state_fits(eng, x.shape[0]):
+        if ab.wants_grad(self, llr) and ab.saved_state_fits(eng, x.shape[0]):
             # posterior with a grad_fn back to the edge weights, as in the reference (neural_minsum_decoder.py:100-139)
             g, T = self.code.tanner_graph(), int(self.max_iterations)
             rows, cols = g.check_of_edge.tolist(), g.var_idx.tolist()
@@ -109,7 +109,7 @@ class _EdgeWeightDecoder(nn.Module):
             bt = ab.table_from_params(params, where, (max(T, 1), max(g.E, 1)), 0.0)
             at = torch.ones((max(T, 1), 1), dtype=torch.float32)
             post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, x.detach().to(device=eng.device, dtype=torch.float32),
-                                                        bool(early_stop))
+                                                        bool(early_stop), False, x if x.requires_grad else None)
             if single:
                 return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
             return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)

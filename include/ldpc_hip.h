@@ -159,6 +159,7 @@ int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t ou
  * ldpc_backward      : grad_posterior[batch][n] fp32 (d loss / d posterior) and the
  *   iterations[batch] that decode returned -> grad_beta[T][n_beta_slots], grad_alpha[T][n_alpha_slots]
  *   fp32 and, for LDPC_C2V_OMS decoders created with oms_alpha, grad_oms_alpha[T][n_oms_alpha_slots]
+ *   and grad_llr[batch][n] fp32 (d loss / d llr, for callers that train what produces the LLRs)
  *   (device, overwritten; any may be NULL).  The decoder's tables must be the ones the
  *   forward call used.  Slots autograd would leave without a gradient come back as 0.
  * Both need ldpc_train_workspace_bytes of 256-byte aligned scratch; `saved` is 256-byte aligned. */
@@ -170,8 +171,8 @@ int ldpc_decode_saving(const ldpc_decoder *d, const void *llr, int64_t batch, in
                        void *stream);
 int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, const void *llr,
                   int64_t batch, const int32_t *iterations, const void *grad_posterior,
-                  void *grad_beta, void *grad_alpha, void *grad_oms_alpha, void *workspace,
-                  size_t workspace_bytes, void *stream);
+                  void *grad_beta, void *grad_alpha, void *grad_oms_alpha, void *grad_llr,
+                  void *workspace, size_t workspace_bytes, void *stream);
 
 const char *ldpc_last_error(void);
 int ldpc_abi_version(void);

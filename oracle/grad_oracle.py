@@ -46,7 +46,7 @@ def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_sto
     offset=True : C2V = prod(signs) * (relu(minval - beta) - alpha), alpha_slot per EDGE, plain V2C sums
                   (Neural2DOffsetMinSumDecoder, neural_2d_decoder.py:389-412; NeuralOffsetMinSumDecoder with alpha = 0).
     Returns (posterior [B, n] with grad_fn, bits int32 [B, n], iterations int64 [B])."""
-    llr = torch.as_tensor(llr, dtype=dtype)
+    llr = llr if isinstance(llr, torch.Tensor) else torch.as_tensor(llr, dtype=dtype)
     B, n = llr.shape
     E = g.E
     ce, ve = _padded_neighbourhoods(g)
@@ -124,13 +124,18 @@ def bce_loss_sum(posterior, targets=None):
 
 
 def table_grads(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_stop=True, targets=None,
-                dtype=torch.float32, offset=False):
-    """-> (grad beta [T, Sb], grad alpha [T, Sa], posterior, iterations) for bce_loss_sum"""
+                dtype=torch.float32, offset=False, want_llr=False):
+    """-> (grad beta [T, Sb], grad alpha [T, Sa], posterior, iterations[, grad llr [B, n]]) for bce_loss_sum"""
     bt = torch.tensor(np.asarray(beta_table), dtype=dtype, requires_grad=True)
     at = torch.tensor(np.asarray(alpha_table), dtype=dtype, requires_grad=True)
-    post, bits, iters = forward(g, llr, bt, beta_slot, at, alpha_slot, T, early_stop, dtype, offset)
+    x = torch.tensor(np.asarray(llr), dtype=dtype, requires_grad=want_llr)
+    post, bits, iters = forward(g, x, bt, beta_slot, at, alpha_slot, T, early_stop, dtype, offset)
     loss = bce_loss_sum(post, None if targets is None else torch.as_tensor(targets))
-    gb, ga = torch.autograd.grad(loss, (bt, at), allow_unused=True)
-    gb = torch.zeros_like(bt) if gb is None else gb
-    ga = torch.zeros_like(at) if ga is None else ga
-    return gb.detach().numpy(), ga.detach().numpy(), post.detach().numpy(), iters.numpy()
+    wrt = (bt, at, x) if want_llr else (bt, at)
+    grads = torch.autograd.grad(loss, wrt, allow_unused=True)
+    gb = torch.zeros_like(bt) if grads[0] is None else grads[0]
+    ga = torch.zeros_like(at) if grads[1] is None else grads[1]
+    out = (gb.detach().numpy(), ga.detach().numpy(), post.detach().numpy(), iters.numpy())
+    if want_llr:
+        out += ((torch.zeros_like(x) if grads[2] is None else grads[2]).detach().numpy(),)
+    return out

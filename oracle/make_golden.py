@@ -722,6 +722,53 @@ def gen_grad(which):
     return out
 
 
+def gen_grad_llr():
+    """d loss/d llr of the reference (its forward is differentiable in the input too): Neural2D type 2, the offset
+    decoder type 2 and the per-edge decoder on the toy code"""
+    import torch.nn.functional as F
+    import grad_oracle
+    rng = np.random.default_rng(9753)
+    code = ref_ldpc.create_test_ldpc_code()
+    H = code.H
+    g = oracle.OracleGraph(H)
+    llrs = np.concatenate([toy_inputs_fp64(32)[10:18].astype(np.float32), rng.normal(0.8, 1.6, (6, 7)).astype(np.float32)])
+    out = {"H": H.astype(np.uint8), "llr": llrs}
+
+    def run(dec):
+        gl, its = [], []
+        for x in llrs:
+            dec.zero_grad()
+            t = torch.from_numpy(x.copy()).requires_grad_(True)
+            _, p, i = dec(t)
+            F.binary_cross_entropy_with_logits(-p, torch.zeros_like(p)).backward()
+            gl.append(t.grad.numpy().copy()); its.append(int(i))
+        return np.stack(gl), np.asarray(its, np.int32)
+
+    T = 4
+    dec = ref_n2d.Neural2DMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+    beta, alpha = set_weights(dec, rng)
+    gl, its = run(dec)
+    bt, bs, at, as_ = oracle.weight_tables(g, 2, T, beta, alpha)
+    og = grad_oracle.table_grads(g, llrs, bt, bs, at, as_, T, want_llr=True)
+    check_equal("grad llr iters", og[3].astype(np.int32), its)
+    if not np.allclose(og[4], gl, rtol=2e-4, atol=2e-6):
+        raise SystemExit("GRAD ORACLE MISMATCH: d loss/d llr (n2d)")
+    bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+    out.update(n2d_T=np.int32(T), n2d_iters=its, n2d_grad_llr=gl, n2d_beta_keys=bk, n2d_beta_vals=bv, n2d_alpha_keys=ak, n2d_alpha_vals=av)
+
+    dec = ref_n2d.Neural2DOffsetMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+    beta, alpha = set_weights(dec, rng, 0.0, 0.6, 0.0, 0.3)
+    gl, its = run(dec)
+    bt, bs, at, as_ = oracle.weight_tables(g, 2, T, beta, alpha, beta_default=0.0, alpha_default=0.0)
+    og = grad_oracle.table_grads(g, llrs, bt, bs, at, as_[g.var_idx], T, offset=True, want_llr=True)
+    check_equal("grad llr iters (oms)", og[3].astype(np.int32), its)
+    if not np.allclose(og[4], gl, rtol=2e-4, atol=2e-6):
+        raise SystemExit("GRAD ORACLE MISMATCH: d loss/d llr (oms2d)")
+    bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+    out.update(oms_T=np.int32(T), oms_iters=its, oms_grad_llr=gl, oms_beta_keys=bk, oms_beta_vals=bv, oms_alpha_keys=ak, oms_alpha_vals=av)
+    return out
+
+
 SETS = {
     "quantizer": gen_quantizer,
     "sums": gen_sums,
@@ -741,6 +788,7 @@ SETS = {
     "grad_toy": lambda: gen_grad("toy"),
     "grad_small": lambda: gen_grad("small"),
     "grad_ira": lambda: gen_grad("ira"),
+    "grad_llr_toy": gen_grad_llr,
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 

@@ -300,3 +300,64 @@ def test_second_backward_needs_recycling_off(gpu_device):
             assert g2[k] == pytest.approx(2 * g1[k], rel=1e-5, abs=1e-7)
     finally:
         ab.RECYCLE_SAVED = True
+
+
+@pytest.mark.parametrize("kind", ["n2d", "oms"])
+def test_golden_input_gradient(gpu_device, kind):
+    """d loss/d llr through loss.backward(), batched on the GPU and one CPU vector at a time, against the reference"""
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
+    gold = load_golden("grad_llr_toy")
+    T = int(gold[f"{kind}_T"])
+    dec = (Neural2DMinSumDecoder if kind == "n2d" else Neural2DOffsetMinSumDecoder)(make_code(gold, T), 2, T)
+    sd = {f"beta_weights.{k}": torch.tensor([v]) for k, v in weights_dict(gold[f"{kind}_beta_keys"], gold[f"{kind}_beta_vals"]).items()}
+    sd.update({f"alpha_weights.{k}": torch.tensor([v])
+               for k, v in weights_dict(gold[f"{kind}_alpha_keys"], gold[f"{kind}_alpha_vals"]).items()})
+    dec.load_state_dict(sd)
+    x = torch.from_numpy(gold["llr"]).to(gpu_device).requires_grad_(True)
+    _, post, iters = dec(x)
+    np.testing.assert_array_equal(iters.cpu().numpy(), gold[f"{kind}_iters"])
+    codeword_loss_sum(post).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gold[f"{kind}_grad_llr"], rtol=1e-4, atol=2e-6)
+    for p in dec.parameters():                       # frozen weights, trainable front end: only the input gradient flows
+        p.requires_grad_(False)
+    x1 = torch.from_numpy(gold["llr"][3].copy()).requires_grad_(True)
+    _, p1, _ = dec(x1)
+    assert p1.requires_grad and p1.device.type == "cpu"
+    F.binary_cross_entropy_with_logits(-p1, torch.zeros_like(p1)).backward()
+    np.testing.assert_allclose(x1.grad.numpy(), gold[f"{kind}_grad_llr"][3], rtol=1e-4, atol=2e-6)
+
+
+def test_input_gradient_vs_oracle_on_the_1998_code(gpu_device):
+    import codes
+    import grad_oracle
+    import oracle
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    T, B = 4, 70
+    code = codes.load_code("ira_1998_1512", max_iterations=T)
+    dec = Neural2DMinSumDecoder(code, 2, T)
+    rng = np.random.default_rng(5)
+    with torch.no_grad():
+        for p in dec.beta_weights.values():
+            p.fill_(float(rng.uniform(0.5, 1.0)))
+        for p in dec.alpha_weights.values():
+            p.fill_(float(rng.uniform(0.8, 1.2)))
+    snr = np.where(np.arange(B) % 2 == 0, 2.0, 6.5)
+    s2 = 10.0 ** (-snr / 10.0)
+    llr = (2.0 * (1.0 + np.sqrt(s2)[:, None] * rng.standard_normal((B, code.n))) / s2[:, None]).astype(np.float32)
+    eng = dec._get_engine(gpu_device)
+    x = torch.from_numpy(llr).to(gpu_device)
+    res, saved = eng.decode_saving(x, early_stop=True)
+    tg = code.tanner_graph()
+    g = oracle.OracleGraph(n=code.n, check_ptr=tg.check_ptr, var_idx=tg.var_idx)
+    bt_np, at_np = dec.weight_tables()
+    lay = dec._sharing_layout()
+    xt = torch.tensor(llr, requires_grad=True)
+    post, _, iters = grad_oracle.forward(g, xt, torch.tensor(bt_np), lay.beta_slot, torch.tensor(at_np), lay.alpha_slot, T, True)
+    agree = (iters.numpy() == res.iterations.cpu().numpy()) & \
+        np.all(np.abs(post.detach().numpy() - res.posterior.cpu().numpy()) <= 1e-4 * np.maximum(1, np.abs(post.detach().numpy())), axis=1)
+    assert agree.mean() > 0.95
+    gpost = (rng.standard_normal((B, code.n)).astype(np.float32)) * agree[:, None]
+    (post * torch.from_numpy(gpost)).sum().backward()
+    _, _, _, gl = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost).to(gpu_device), want_grad_llr=True)
+    want = xt.grad.numpy()
+    np.testing.assert_allclose(gl.cpu().numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max())

@@ -171,3 +171,23 @@ def test_training_abi_is_declared_and_refuses_to_run_without_a_gpu():
         with pytest.raises(Exception) as e:                       # grad-enabled call: still no CPU fallback
             dec(torch.zeros(7))
         assert "GPU" in str(e.value) or "HIP" in str(e.value) or "cuda" in str(e.value).lower()
+
+
+def test_gradient_oracle_input_gradient_equals_reference_autograd(oracle_mod):
+    """d loss/d llr (the reference's forward is differentiable in its input too)"""
+    import grad_oracle
+    gold = load_golden("grad_llr_toy")
+    g = _graph(gold, oracle_mod)
+    T = int(gold["n2d_T"])
+    bt, bs, at, as_ = oracle_mod.weight_tables(g, 2, T, weights_dict(gold["n2d_beta_keys"], gold["n2d_beta_vals"]),
+                                               weights_dict(gold["n2d_alpha_keys"], gold["n2d_alpha_vals"]))
+    out = grad_oracle.table_grads(g, gold["llr"], bt, bs, at, as_, T, want_llr=True)
+    np.testing.assert_array_equal(out[3], gold["n2d_iters"])
+    np.testing.assert_allclose(out[4], gold["n2d_grad_llr"], rtol=2e-4, atol=2e-6)
+    T = int(gold["oms_T"])
+    bt, bs, at, as_ = oracle_mod.weight_tables(g, 2, T, weights_dict(gold["oms_beta_keys"], gold["oms_beta_vals"]),
+                                               weights_dict(gold["oms_alpha_keys"], gold["oms_alpha_vals"]),
+                                               beta_default=0.0, alpha_default=0.0)
+    out = grad_oracle.table_grads(g, gold["llr"], bt, bs, at, as_[g.var_idx], T, offset=True, want_llr=True)
+    np.testing.assert_array_equal(out[3], gold["oms_iters"])
+    np.testing.assert_allclose(out[4], gold["oms_grad_llr"], rtol=2e-4, atol=2e-6)
