@@ -1003,7 +1003,8 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     if (grad_llr)
         HIP_TRY(hipMemcpyAsync(w.gllrT, w.gpostT, (size_t)w.tiles * W * g.n * sizeof(float), hipMemcpyDeviceToDevice, s));
     const int cb = (g.m + kWavesPerBlock - 1) / kWavesPerBlock, vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
-    const dim3 cgrid((unsigned)((size_t)w.tiles * cb)), vgrid((unsigned)((size_t)w.tiles * vb));
+    const int vbb = (g.n + kWavesPerBlock * kVnbVarsPerWave - 1) / (kWavesPerBlock * kVnbVarsPerWave);   // vn_backward: several variables per wave
+    const dim3 cgrid((unsigned)((size_t)w.tiles * cb)), vgrid((unsigned)((size_t)w.tiles * vb)), vbgrid((unsigned)((size_t)w.tiles * vbb));
     const size_t epart = (size_t)w.tiles * g.E, vpart = (size_t)w.tiles * g.n;
     for (int t = T - 1; t >= 0; --t) {
         const float *beta_row = (const float *)d->beta + (size_t)t * d->n_beta;
@@ -1021,9 +1022,9 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
             if (oms) LDPC_CNB(false, FORM_OMS, saved + sl.v2c_off(t), w.gv2c);
             else LDPC_CNB(false, FORM_NMS, saved + sl.v2c_off(t), w.gv2c);
             const float *alpha_row = (const float *)d->alpha + (size_t)(t - 1) * d->n_alpha;
-            hipLaunchKernelGGL((vn_backward<VEC>), vgrid, blk, 0, s, g, (const float *)(saved + sl.c2v_off(t - 1)),
+            hipLaunchKernelGGL((vn_backward<VEC>), vbgrid, blk, 0, s, g, (const float *)(saved + sl.c2v_off(t - 1)),
                                (const float *)w.gv2c, iterations, (long long)batch, t, alpha_row, (const int *)d->alpha_slot,
-                               w.gc2v, w.galpha + (size_t)(t - 1) * vpart, vb);
+                               w.gc2v, w.galpha + (size_t)(t - 1) * vpart, vbb);
         }
         if (grad_llr)                                     // g_llr += sum over the edges of every variable of g_v2c_t
             hipLaunchKernelGGL((llr_backward_accumulate<VEC>), vgrid, blk, 0, s, g, (const float *)w.gv2c, w.gllrT, vb);

@@ -193,6 +193,8 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
 // in: c2v_t-1 rows, d loss/d v2c_t rows.  out: d loss/d c2v_t-1 rows, per-variable partial of
 // d loss/d alpha_t-1.  Leave-one-out sums are formed as (total - own) with the totals in fp64.
 // ------------------------------------------------------------------------------------------
+constexpr int kVnbVarsPerWave = 4;
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *__restrict__ c2v_prev,
                                                       const float *__restrict__ gv2c,
@@ -205,14 +207,8 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     constexpr int W = kWave * VEC;
     const int lane = threadIdx.x & (kWave - 1);
     const int tile = uni(blockIdx.x / var_blocks);
-    const int j = uni((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
-    if (j >= g.n) return;
-    const int k0 = uni(g.var_ptr[j]);
-    const int dv = uni(g.var_ptr[j + 1]) - k0;
-    if (dv == 0) {
-        if (lane == 0) galpha_part[(size_t)tile * g.n + j] = 0.0f;
-        return;
-    }
+    const int jbase = uni(((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * kVnbVarsPerWave);
+    if (jbase >= g.n) return;
     int state[VEC];
     load_states<VEC>(iterations, batch, tile, lane, t, state);     // v2c_t exists for codewords with state != 0
     bool mine = false;
@@ -220,13 +216,22 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     for (int c = 0; c < VEC; ++c) mine |= state[c] != 0;
     const bool any = __ballot(mine) != 0ull;
     const size_t base = (size_t)tile * g.E * W + (size_t)lane * VEC;
+    for (int vv = 0; vv < kVnbVarsPerWave; ++vv) {       // a wave's work per variable is small (degree 2-3): several per wave
+    const int j = jbase + vv;
+    if (j >= g.n) break;
+    const int k0 = uni(g.var_ptr[j]);
+    const int dv = uni(g.var_ptr[j + 1]) - k0;
+    if (dv == 0) {
+        if (lane == 0) galpha_part[(size_t)tile * g.n + j] = 0.0f;
+        continue;
+    }
     if (!any) {
         Pack<float, VEC> z;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) z.x[c] = 0.0f;
         for (int k = 0; k < dv; ++k) st<float, VEC>(gc2v_out + base + (size_t)g.csc_edge[k0 + k] * W, z);
         if (lane == 0) galpha_part[(size_t)tile * g.n + j] = 0.0f;
-        return;
+        continue;
     }
     const float alpha = alpha_row[alpha_slot[j]];
     double totc[VEC], totg[VEC];
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
         }
         ga = wave_sum(ga);
         if (lane == 0) galpha_part[(size_t)tile * g.n + j] = ga;
-        return;
+        continue;
     }
 #pragma unroll 4
     for (int k = 0; k < dv; ++k) {
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(kBlock) void vn_backward(GraphDev g, const float *_
     }
     ga = wave_sum(ga);
     if (lane == 0) galpha_part[(size_t)tile * g.n + j] = ga;
+    }   // variables of this wave
 }
 
 // d loss/d llr: the LLR of variable j enters the returned posterior directly and every v2c message of j
