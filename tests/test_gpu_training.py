@@ -361,3 +361,48 @@ def test_input_gradient_vs_oracle_on_the_1998_code(gpu_device):
     _, _, _, gl = eng.backward(saved, x, res.iterations, torch.from_numpy(gpost).to(gpu_device), want_grad_llr=True)
     want = xt.grad.numpy()
     np.testing.assert_allclose(gl.cpu().numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("wtype", [1, 2])
+def test_gradients_on_wide_checks_and_high_degree_variables(gpu_device, wtype):
+    """check degrees > 32 (the backward sweep re-reads rows instead of using its 32-edge masks), variable degrees > 8
+    (two-pass variable backward), a degree-1 check, an empty check, an isolated and a degree-1 variable"""
+    import grad_oracle
+    import oracle
+    from ldpc_decoder import LDPCCode
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    rng = np.random.default_rng(12)
+    H = (rng.random((12, 40)) < 0.9).astype(np.int64)
+    H[10, :] = 0; H[10, 5] = 1
+    H[11, :] = 0
+    H[:, 39] = 0
+    H[:, 38] = 0; H[0, 38] = 1
+    T, B = 3, 20
+    code = LDPCCode(n=40, k=28, H=H, max_iterations=T)
+    og = oracle.OracleGraph(H)
+    assert og.dc.max() > 32 and og.dv.max() > 8
+    dec = Neural2DMinSumDecoder(code, wtype, T)
+    with torch.no_grad():
+        for p in dec.beta_weights.values():
+            p.fill_(float(rng.uniform(0.05, 0.2)))       # dense graph: small factors keep the messages bounded
+        for p in dec.alpha_weights.values():
+            p.fill_(float(rng.uniform(0.8, 1.2)))
+    llr = (rng.standard_normal((B, 40)) * 2 + 0.5).astype(np.float32)
+    x = torch.from_numpy(llr).to(gpu_device).requires_grad_(True)
+    _, post, iters = dec(x)
+    codeword_loss_sum(post).backward()
+    bt_np, at_np = dec.weight_tables()
+    lay = dec._sharing_layout()
+    gb, ga, opost, oit, gl = grad_oracle.table_grads(og, llr, bt_np, lay.beta_slot, at_np, lay.alpha_slot, T, want_llr=True)
+    np.testing.assert_array_equal(iters.cpu().numpy(), oit)
+    np.testing.assert_allclose(post.detach().cpu().numpy(), opost, rtol=1e-4, atol=1e-4)
+    for t in range(T):
+        for s_, suf in enumerate(lay.beta_suffix):
+            if suf is not None:
+                got = dec.beta_weights[f"iter_{t}_{suf}"].grad.item()
+                assert abs(got - gb[t, s_]) <= 1e-5 + 1e-3 * abs(gb[t, s_]), ("beta", t, suf, got, gb[t, s_])
+        for s_, suf in enumerate(lay.alpha_suffix):
+            if suf is not None:
+                got = dec.alpha_weights[f"iter_{t}_{suf}"].grad.item()
+                assert abs(got - ga[t, s_]) <= 1e-5 + 1e-3 * abs(ga[t, s_]), ("alpha", t, suf, got, ga[t, s_])
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gl, rtol=1e-3, atol=1e-5)
