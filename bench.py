@@ -1,33 +1,37 @@
 #!/usr/bin/env python3
 """
-bench.py -- decoded codewords/s at fixed iterations + HBM roofline of the dominant kernel.
+bench.py -- decoded codewords/s at fixed iterations + roofline of the dominant kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload basic|neural2d|rcq|wrcq_dvbs2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload basic|neural2d|rcq|wrcq_dvbs2|basic_f64]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = ONE decode of one batch of synthetic LLRs (already resident in HBM) through the
-hot path: layout change, T x (check sweep + variable sweep), syndrome, hard decisions out.
+hot path: T iterations of check + variable updates, syndrome, hard decisions out.
 Default workload = BASELINE.json configs[1]: (1998,1512) code, BasicMinSumDecoder factor 0.7,
 fp32, 10 iterations, batch 65536 per GPU, SNR 2.0 dB, fixed iterations (early_stop=False).
-N > 1: weak scaling, every rank decodes its own 65536 codewords and the step ends with the
-RCCL all-gather of the bit-packed hard decisions; value = all ranks' codewords / max-rank time.
 
-Two engines implement the path (identical results): the LDS-resident fused kernel (codes whose
-state fits LDS, e.g. the (1998,1512) code) and the HBM-streaming sweep kernels (any code).  The
-step uses whichever the library picks (config.engine); with the resident engine the streaming
-engine is measured too and reported under "stream_engine".
+N > 1: one process per GPU.  Started bare (`python bench.py --gpus N`, no WORLD_SIZE in the
+environment) the script spawns its N ranks itself as child processes BEFORE anything touches the
+GPU, relays rank 0's JSON line and exits non-zero if a rank fails; started under
+torch.distributed.run it is one of the ranks.  Weak scaling by default (every rank decodes its own
+batch; `--strong` splits --batch over the ranks); every step ends with the RCCL all-gather of
+the bit-packed hard decisions; value = all ranks' codewords / max-rank time.
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline     : the dominant kernel timed live with HIP events on its stream; ALGORITHMIC bytes
-                 of SURVEY 8d (CN sweep: 8E per codeword fp32, 5E RCQ; whole decode:
-                 T(16E+4n)+8n) / time vs 8 TB/s
+  roofline     : the dominant kernel of the timed step, timed live with HIP events on its stream.
+                 LDS-resident engine: bound "lds" (conflict-free LDS time of its iteration phases / measured
+                 time), its real HBM rate under "hbm" and the SURVEY 8d byte model under "hbm_formulation_equiv";
+                 streaming engine: bound "hbm", ALGORITHMIC bytes of the CN sweep (8E per codeword fp32, 5E RCQ)
+  stream_engine: the HBM-streaming engine on the same workload with the CN->VN sweep's HBM roofline (north_star)
+  workloads    : bounded legs for the other BASELINE configs (Neural-2D, RCQ, (16200,7200) W-RCQ, fp64 Basic)
   cpu_baseline : the CPU oracle (C port of the reference loops) on a bounded sample
 """
 import argparse
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,24 +41,78 @@ for p in (PKG_DIR, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 QP = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
+METRIC = "decoded codewords/sec at fixed iters; achieved HBM GB/s vs peak"
 
 WORKLOADS = {
-    # name: (graph, iterations, default batch per GPU, description)
-    "basic": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, BasicMinSumDecoder factor=0.7, fp32"),
-    "neural2d": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, Neural2DMinSumDecoder type 2, fp32"),
-    "rcq": ("ira_1998_1512", 10, 65536, "(1998,1512) IRA code, RCQMinSumDecoder bc=3 bv=8, 3 quantisers"),
-    "wrcq_dvbs2": ("dvbs2_like_16200_7200", 20, 32768, "(16200,7200) DVB-S2-like code, WeightedRCQDecoder type 2 bc=3"),
+    # name: (graph, iterations, default batch per GPU, arithmetic, description)
+    "basic": ("ira_1998_1512", 10, 65536, "f32", "(1998,1512) IRA code, BasicMinSumDecoder factor=0.7, fp32"),
+    "neural2d": ("ira_1998_1512", 10, 65536, "f32", "(1998,1512) IRA code, Neural2DMinSumDecoder type 2, fp32"),
+    "rcq": ("ira_1998_1512", 10, 65536, "f32", "(1998,1512) IRA code, RCQMinSumDecoder bc=3 bv=8, 3 quantisers"),
+    "wrcq_dvbs2": ("dvbs2_like_16200_7200", 20, 32768, "f32", "(16200,7200) DVB-S2-like code, WeightedRCQDecoder type 2 bc=3"),
+    "basic_f64": ("ira_1998_1512", 10, 65536, "f64", "(1998,1512) IRA code, BasicMinSumDecoder factor=0.7, float64 as in the reference"),
 }
+LEGS = ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64")       # secondary legs of the default single-GPU run
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="basic")
+    ap.add_argument("--batch", type=int, default=0, help="codewords per GPU (default: the workload's)")
+    ap.add_argument("--snr-db", type=float, default=2.0)
+    ap.add_argument("--early-stop", action="store_true", help="reference early-exit semantics instead of fixed T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-reps", type=int, default=20)
+    ap.add_argument("--no-overlap", action="store_true", help="join every step's all-gather before the next decode")
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
+    ap.add_argument("--no-legs", action="store_true", help="skip the legs for the other BASELINE configs")
+    ap.add_argument("--leg-steps", type=int, default=5)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the all-gather path even with one rank (checks the RCCL plumbing on a single GPU)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch (default: the workload's) is the TOTAL over all GPUs, split evenly")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------- self-launch
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` started bare: run the N ranks as CHILD processes (one per GPU) and relay rank 0's
+    JSON line.  This parent never touches the GPU (no HIP call, no torch.cuda call) -- nothing is re-exec'ed."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode(errors="replace")
+    codes = [p.wait() for p in procs]
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if any(codes) or len(lines) != 1:
+        sys.stderr.write(f"bench.py: rank exit codes {codes}, {len(lines)} result line(s)\n")
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(1)
+    print(lines[0], flush=True)
+
+
+# ----------------------------------------------------------------------------------- workload construction
 def synthetic_tables(dec, seed=4321):
     """'pretrained' weights stand-in: beta ~ U(0.5,1), alpha ~ U(0.8,1.2)"""
+    import numpy as np
+    import torch
     rng = np.random.default_rng(seed)
     with torch.no_grad():
         for k in sorted(dec.beta_weights.keys()):
@@ -64,16 +122,17 @@ def synthetic_tables(dec, seed=4321):
 
 
 def build_decoder(workload, device):
-    """-> (engine, host decoder, graph, oracle call for the CPU baseline)"""
+    """-> (engine, host decoder, code)"""
+    import torch
     import codes
     from ldpc_decoder import BasicMinSumDecoder
     from neural_2d_decoder import Neural2DMinSumDecoder
     from rcq_decoder import RCQMinSumDecoder, WeightedRCQDecoder
-    gname, T, _, _ = WORKLOADS[workload]
+    gname, T = WORKLOADS[workload][:2]
     code = codes.load_code(gname, max_iterations=T)
-    if workload == "basic":
+    if workload in ("basic", "basic_f64"):
         dec = BasicMinSumDecoder(code, factor=0.7)
-        eng = dec._engine(torch.float32, device)
+        eng = dec._engine(torch.float64 if workload == "basic_f64" else torch.float32, device)
     elif workload == "neural2d":
         dec = Neural2DMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
         synthetic_tables(dec)
@@ -88,35 +147,156 @@ def build_decoder(workload, device):
     return eng, dec, code
 
 
-def make_llr(batch, n, snr_db, seed, device):
+def make_llr(batch, n, snr_db, seed, device, dtype=None):
     """all-zero codeword, decoder convention (+LLR = bit 0): llr = 2(1 + sigma z)/sigma^2"""
+    import torch
     s2 = 10.0 ** (-snr_db / 10.0)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     z = torch.randn((batch, n), generator=gen, device=device, dtype=torch.float32)
-    return (2.0 * (1.0 + (s2 ** 0.5) * z) / s2).contiguous()
+    x = (2.0 * (1.0 + (s2 ** 0.5) * z) / s2).contiguous()
+    return x if dtype in (None, torch.float32) else x.to(dtype)
 
 
-def resident_lds_model(g, T, B, G, ms):
+def wants_posterior(workload):
+    return workload in ("neural2d", "wrcq_dvbs2")      # those decoders return the posterior
+
+
+def byte_model(workload, g, T, B):
+    """SURVEY 8d ALGORITHMIC bytes (reference formulation: messages through HBM once per sweep)"""
+    es = 8 if workload == "basic_f64" else 4
+    rcq_like = workload in ("rcq", "wrcq_dvbs2")
+    c2v = 1 if rcq_like else es
+    per_iter = 2 * (es + c2v) * g.E + es * g.n                    # fp32: 16E + 4n, RCQ: 10E + 4n
+    return {"decode": (T * per_iter + (es + 4) * g.n) * B,        # + posterior and int32 decisions out
+            "cn_sweep": (es + c2v) * g.E * B,                      # read v2c, write c2v
+            "vn_sweep": ((es + c2v) * g.E + es * g.n) * B,         # read c2v + llr, write v2c
+            "iteration": per_iter * B,
+            "compulsory_io": (es + 4) * g.n * B}                   # LLRs in, int32 decisions out (fused engine)
+
+
+def resident_lds_model(g, T, B, G, ms, es=4):
     """What bounds the fused kernel itself: LDS traffic of its phases against the LDS rates of MI355X_MICROARCH.md
     ("LDS": ds_read_b64 256 B/clk/CU, ds_write_b64 ~85 B/clk/CU, 256 CUs at 2.4 GHz), conflict-free.  Slots are
-    4*G bytes; per codeword group and iteration the check phase reads every slot twice and writes it once, the
+    es*G bytes; per codeword group and iteration the check phase reads every slot twice and writes it once, the
     variable phase reads every slot and its LLR once and writes every slot once."""
-    slot = 4 * G
+    slot = es * G
     groups = (B + G - 1) // G
     reads = groups * slot * (T * 2 * g.E + T * (g.E + g.n))          # bytes
     writes = groups * slot * (T * g.E + T * g.E)
     rd_peak, wr_peak = 256 * 256 * 2.4e9, 85 * 256 * 2.4e9             # B/s, all CUs
     t_min = reads / rd_peak + writes / wr_peak
-    return {"bound": "lds", "lds_read_bytes": reads, "lds_write_bytes": writes, "lds_min_ms": t_min * 1e3,
-            "frac": t_min * 1e3 / ms,
-            "note": "conflict-free LDS time of the iteration phases / measured kernel time; the variable phase's gathers "
-                    "and scatters take ~2 LDS passes per instruction, the rest is VALU issue and barriers"}
+    return reads, writes, t_min * 1e3
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the PMC passes of the latest profiled build (profiles/traffic.json, written by
+    tools/summarize_rocprof.py with the gfx950 correction); every number carries the file it came from"""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tf)).get(workload, {})
+    except Exception:
+        return {}
+
+
+def traffic_of(db, kernel, workload=None, B=None):
+    """(bytes per launch, source file) -- only for the batch the PMC passes ran at (the workload's default)"""
+    ent = db.get(kernel)
+    if isinstance(ent, dict) and (workload is None or B == WORKLOADS[workload][2]):
+        return ent.get("bytes_per_launch"), ent.get("source")
+    return None, None
+
+
+def event_ms(fn, reps, torch):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def stream_roofline(engine, workload, g, T, B, llr, reps, copy_gbs, torch):
+    """CN / VN kernels of the streaming engine, timed live with HIP events on the stream they are launched on
+    (torch's current stream).  RCQ decoders run the fused iteration kernel (cn_gather) instead of the two sweeps."""
+    engine.decode(llr, early_stop=False, want_posterior=False)          # leaves valid state in the workspace
+    bm = byte_model(workload, g, T, B)
+    db = load_traffic(workload)
+    info = engine.info()
+    it = 1 if T > 1 else 0
+    times = {}
+    for which, name in ((0, "cn"), (1, "vn")):
+        for _ in range(3):
+            engine.debug_sweep(B, which, it)
+        times[name] = event_ms(lambda: engine.debug_sweep(B, which, it), reps, torch)
+    if info.get("stream_form") == "fused-rcq-iteration" and it >= 1:
+        # one kernel = one whole iteration; what it must move through HBM is the LLRs and the code bytes in and out
+        es = 4
+        compulsory = (es * g.n + 2 * g.E) * B
+        ach = compulsory / (times["cn"] * 1e-3) / 1e9
+        tr, src = traffic_of(db, "cn_gather", workload, B)
+        return {"bound": "hbm", "kernel": "ldpc::cn_gather (fused RCQ iteration: V2C recomputed from the 1-byte codes + LLRs, "
+                                          "CN->VN codes written; streaming engine)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": compulsory, "ms_per_launch": times["cn"],
+                "traffic": tr, "traffic_source": src,
+                "measured_copy_GBps": copy_gbs,
+                "hbm_formulation_equiv": {"bytes_per_launch": bm["iteration"],
+                                          "achieved": bm["iteration"] / (times["cn"] * 1e-3) / 1e9,
+                                          "frac": bm["iteration"] / (times["cn"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "SURVEY 8d bytes of one iteration in the two-sweep formulation (10E+4n per codeword) "
+                                                  "over this kernel's time; the kernel itself re-reads LLR/code rows through L2/MALL "
+                                                  "and moves 4n+2E distinct bytes per codeword"},
+                "posterior_pass": {"ms_per_launch": times["vn"]}}
+    ach = bm["cn_sweep"] / (times["cn"] * 1e-3) / 1e9
+    tr, src = traffic_of(db, "cn_sweep", workload, B)
+    return {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep, streaming engine)",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": ach / copy_gbs if copy_gbs else None,
+            "traffic": tr, "traffic_source": src,
+            "algorithmic_bytes_per_launch": bm["cn_sweep"], "ms_per_launch": times["cn"],
+            "vn_sweep": {"ms_per_launch": times["vn"],
+                         "achieved": bm["vn_sweep"] / (times["vn"] * 1e-3) / 1e9,
+                         "algorithmic_bytes_per_launch": bm["vn_sweep"]}}
+
+
+def resident_roofline(eng, workload, g, T, B, ms, copy_gbs):
+    """The fused kernel keeps every message in LDS: its limiter is LDS / instruction issue, not HBM.  `frac` is the
+    conflict-free LDS time of its iteration phases over the measured time; the real HBM rate and the SURVEY 8d byte
+    model (which this kernel does not move) are reported beside it under their own names."""
+    es = 8 if workload == "basic_f64" else 4
+    info = eng.info()
+    G = max(info["codewords_per_workgroup"], 1)
+    reads, writes, t_min = resident_lds_model(g, T, B, G, ms, es=es)
+    bm = byte_model(workload, g, T, B)
+    db = load_traffic(workload)
+    tr, src = traffic_of(db, "resident_decode", workload, B)
+    hbm_bytes = tr if tr else bm["compulsory_io"]
+    lds_ach = (reads + writes) / (ms * 1e-3) / 1e9
+    return {"bound": "lds", "kernel": "ldpc::resident_decode (fused T-iteration decode, messages resident in LDS)",
+            "achieved": lds_ach, "peak": lds_ach * ms / t_min, "unit": "GB/s", "frac": t_min / ms,
+            "ms_per_launch": ms, "lds_read_bytes": reads, "lds_write_bytes": writes, "lds_min_ms": t_min,
+            "traffic": tr, "traffic_source": src,
+            "hbm": {"bytes_per_launch": hbm_bytes, "bytes_kind": "PMC-measured" if tr else "compulsory (LLRs in + decisions out)",
+                    "achieved": hbm_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "frac": hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "hbm_formulation_equiv": {"bytes_per_launch": bm["decode"],
+                                      "achieved": bm["decode"] / (ms * 1e-3) / 1e9,
+                                      "frac": bm["decode"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "SURVEY 8d algorithmic bytes T(16E+4n)+8n per codeword (10E for RCQ) of the "
+                                              "HBM-streaming formulation over this kernel's time -- an equivalence figure, "
+                                              "not traffic: the fused kernel never moves these bytes"},
+            "measured_copy_GBps": copy_gbs,
+            "note": "peak = the blended LDS rate of this read/write mix (ds_read_b64 256 B/clk/CU, ds_write_b64 ~85 B/clk/CU, "
+                    "256 CUs, 2.4 GHz); the variable phase's gathers/scatters take ~2 LDS passes per instruction, the rest "
+                    "is VALU issue and barriers"}
 
 
 def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
     """The CPU oracle (oracle/ldpc_oracle.c, a C port of the reference's loops; the Python
     reference itself cannot travel to the GPU box) on a bounded sample of the same workload."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     oracle.build()
@@ -128,10 +308,11 @@ def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
     threads = oracle.num_threads()
 
     def run(cnt):
-        x = (2.0 * (1.0 + np.sqrt(s2) * rng.standard_normal((cnt, g.n))) / s2).astype(np.float32)
+        x = (2.0 * (1.0 + np.sqrt(s2) * rng.standard_normal((cnt, g.n))) / s2)
+        x = x.astype(np.float64 if workload == "basic_f64" else np.float32)
         t0 = time.perf_counter()
-        if workload == "basic":
-            oracle.basic_minsum(og, x, 0.7, T, early_stop=False, dtype=np.float32)
+        if workload in ("basic", "basic_f64"):
+            oracle.basic_minsum(og, x, 0.7, T, early_stop=False, dtype=x.dtype.type)
         elif workload == "neural2d":
             oracle.neural2d(og, x, 2, T, {k: float(v.item()) for k, v in dec.beta_weights.items()},
                             {k: float(v.item()) for k, v in dec.alpha_weights.items()}, early_stop=False)
@@ -150,24 +331,56 @@ def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
             "sample": f"{cnt} codewords of the same workload, fixed {T} iterations, OpenMP over codewords, {t:.1f} s"}
 
 
+def copy_ceiling(device, torch):
+    """Measured HBM ceiling of this box (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB -> 1 GiB
+    device copy (read + write, far beyond the 256 MB Infinity Cache), best of 6, GB/s"""
+    src = torch.empty(1 << 28, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    best = 0.0
+    for _ in range(6):
+        ms = event_ms(lambda: dst.copy_(src), 1, torch)
+        best = max(best, 2 * src.numel() * 4 / (ms * 1e-3) / 1e9)
+    del src, dst
+    return best
+
+
+def measure_leg(workload, device, snr_db, steps, reps, copy_gbs, with_cpu, torch):
+    """one bounded leg of another BASELINE config on this GPU: decode rate + the roofline of its dominant kernel"""
+    gname, T, B, dtype, desc = WORKLOADS[workload]
+    eng, dec, code = build_decoder(workload, device)
+    g = code.tanner_graph()
+    llr = make_llr(B, g.n, snr_db, 1234, device, torch.float64 if dtype == "f64" else torch.float32)
+    wp = wants_posterior(workload)
+    run = lambda: eng.decode(llr, early_stop=False, want_bits=True, want_posterior=wp)
+    run()
+    torch.cuda.synchronize(device)
+    ms = event_ms(run, steps, torch)
+    res = run()
+    assert int(res.iterations.min().item()) == T
+    leg = {"workload": f"{desc}, {T} iterations, batch {B}, SNR {snr_db} dB, fixed-iteration flooding decode",
+           "dtype": dtype, "batch": B, "steps": steps, "ms_per_step": ms, "value": B / (ms * 1e-3), "unit": "codewords/s",
+           "engine": eng.info(), "edges": g.E, "n": g.n,
+           "decode_algorithmic_GBps": byte_model(workload, g, T, B)["decode"] / (ms * 1e-3) / 1e9}
+    if eng.info()["engine"] == "resident":
+        leg["roofline"] = resident_roofline(eng, workload, g, T, B, ms, copy_gbs)
+    else:
+        leg["roofline"] = stream_roofline(eng, workload, g, T, B, llr, max(reps // 2, 2), copy_gbs, torch)
+    if with_cpu:
+        leg["cpu_baseline"] = cpu_baseline(workload, dec, code, snr_db, budget_s=4.0)
+    del eng, dec, llr, res
+    torch.cuda.empty_cache()
+    return leg
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="basic")
-    ap.add_argument("--batch", type=int, default=0, help="codewords per GPU (default: the workload's)")
-    ap.add_argument("--snr-db", type=float, default=2.0)
-    ap.add_argument("--early-stop", action="store_true", help="reference early-exit semantics instead of fixed T")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep-reps", type=int, default=20)
-    ap.add_argument("--no-overlap", action="store_true", help="join every step's all-gather before the next decode")
-    ap.add_argument("--no-stream-leg", action="store_true", help="skip the secondary streaming-engine measurement")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the process group and run the all-gather path even with one rank (checks the RCCL plumbing on a single GPU)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --batch (default: the workload's) is the TOTAL over all GPUs, split evenly")
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return spawn_ranks(args.gpus, sys.argv[1:])          # before any GPU call in this process
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     # stdout carries exactly ONE line, the JSON result: libraries that print there (RCCL writes a five-line version
     # banner to stdout when its first communicator comes up) are sent to stderr for the duration of the run
@@ -175,12 +388,11 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the decode path has no CPU fallback")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -197,7 +409,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    gname, T, default_batch, desc = WORKLOADS[args.workload]
+    gname, T, default_batch, dtype, desc = WORKLOADS[args.workload]
     B = args.batch or default_batch
     if args.strong:                                              # fixed total work, B / world per GPU
         if B % world:
@@ -205,8 +417,8 @@ def main():
         B //= world
     eng, dec, code = build_decoder(args.workload, device)
     g = code.tanner_graph()
-    llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device)
-    want_post = args.workload in ("neural2d", "wrcq_dvbs2")      # those decoders return the posterior
+    llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device, torch.float64 if dtype == "f64" else torch.float32)
+    want_post = wants_posterior(args.workload)
     early = bool(args.early_stop)
 
     from sharding import all_gather_hard_decisions
@@ -247,7 +459,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -259,125 +471,61 @@ def main():
     if not early:
         assert int(its.min().item()) == T
     frac_ok = float(res.success.float().mean().item())
+    if use_dist and gathered is not None:
+        assert tuple(gathered.shape) == (world * B, nbytes)
 
     out = {
-        "metric": "decoded codewords/sec at fixed iters; achieved HBM GB/s vs peak",
+        "metric": METRIC,
         "value": value, "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"{desc}, {T} iterations, batch {B}/GPU, SNR {args.snr_db} dB, "
                                f"{'early-stop' if early else 'fixed-iteration'} flooding decode",
                    "graph": gname, "n": g.n, "m": g.m, "edges": g.E, "iterations": T,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "collective": "all_gather(bit-packed hard decisions)" if world > 1 else "none",
-                   "converged_fraction": frac_ok},
+                   "collective": ("all_gather(bit-packed hard decisions), " + backend) if use_dist else "none",
+                   "converged_fraction": frac_ok,
+                   "dtype_note": "the reference's BasicMinSumDecoder computes in float64 (numpy default); the benchmark "
+                                 "config is defined on fp32 (BASELINE.json north_star, SURVEY 8d) -- the float64 kernels "
+                                 "run as the `basic_f64` leg; fp32-vs-fp64 decision mismatch rates are in BASELINE.md"},
     }
 
     if rank == 0:
         out["config"]["engine"] = eng.info()
-        rcq_like = args.workload in ("rcq", "wrcq_dvbs2")
-        per_cw_decode = T * ((10 if rcq_like else 16) * g.E + 4 * g.n) + 8 * g.n     # SURVEY 8d, whole decode
-        bytes_cn = (5 if rcq_like else 8) * g.E * B            # CN sweep: read v2c 4E + write c2v 4E (1E as codes)
-        bytes_vn = ((5 if rcq_like else 8) * g.E + 4 * g.n) * B
         reps = max(args.sweep_reps, 1)
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        traffic_db = {}
-        if os.path.exists(tf):
-            try:
-                traffic_db = json.load(open(tf)).get(args.workload, {})
-            except Exception:
-                traffic_db = {}
-
-        def time_sweeps(engine):
-            """CN / VN sweep kernels of the streaming engine, timed live with HIP events on the stream
-            they are launched on (torch's current stream)"""
-            engine.decode(llr, early_stop=False, want_posterior=False)          # leaves valid state in the workspace
-            times = {}
-            for which, name in ((0, "cn_sweep"), (1, "vn_sweep")):
-                for _ in range(3):
-                    engine.debug_sweep(B, which, 1)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    engine.debug_sweep(B, which, 1)
-                e1.record()
-                e1.synchronize()
-                times[name] = e0.elapsed_time(e1) / reps                        # ms per launch
-            return times
-
-        def copy_ceiling():
-            """Measured HBM ceiling of this box (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB -> 1 GiB
-            device copy (read + write, far beyond the 256 MB Infinity Cache), best of 5, GB/s"""
-            src = torch.empty(1 << 28, dtype=torch.float32, device=device).normal_()
-            dst = torch.empty_like(src)
-            best = 0.0
-            for _ in range(6):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                dst.copy_(src)
-                e1.record()
-                e1.synchronize()
-                best = max(best, 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-            del src, dst
-            return best
-
-        copy_gbs = copy_ceiling()
-
-        def stream_roofline(engine):
-            times = time_sweeps(engine)
-            ach = bytes_cn / (times["cn_sweep"] * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep, streaming engine)",
-                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
-                    "traffic": traffic_db.get("cn_sweep_bytes_per_launch"),
-                    "algorithmic_bytes_per_launch": bytes_cn, "ms_per_launch": times["cn_sweep"],
-                    "vn_sweep": {"ms_per_launch": times["vn_sweep"],
-                                 "achieved": bytes_vn / (times["vn_sweep"] * 1e-3) / 1e9,
-                                 "algorithmic_bytes_per_launch": bytes_vn}}
-
+        bm = byte_model(args.workload, g, T, B)
+        copy_gbs = copy_ceiling(device, torch)
+        run = lambda: eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
         if eng.info()["engine"] == "resident":
-            # dominant kernel = ldpc::resident_decode (the whole decode is this one launch): time it with
-            # HIP events; ALGORITHMIC bytes are those of the reference formulation (SURVEY 8d), which this
-            # kernel does not move -- messages stay in LDS -- hence frac can exceed 1 and `traffic` << them.
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            ach = per_cw_decode * B / (ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "ldpc::resident_decode (fused T-iteration decode, messages resident in LDS)",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic_db.get("resident_decode_bytes_per_launch"),
-                               "measured_copy_GBps": copy_gbs,
-                               "algorithmic_bytes_per_launch": per_cw_decode * B, "ms_per_launch": ms,
-                               "own_limiter": resident_lds_model(g, T, B, eng.info()["codewords_per_workgroup"], ms),
-                               "note": "algorithmic bytes = T(16E+4n)+8n per codeword (10E for RCQ) of the HBM-streaming "
-                                       "formulation; the fused kernel keeps messages in LDS, so frac > 1 means it beats "
-                                       "the HBM roofline of that formulation; its own limiter is LDS/instruction issue"}
+            # dominant kernel = ldpc::resident_decode (the whole decode is this one launch), timed with HIP events
+            ms = event_ms(run, reps, torch)
+            out["roofline"] = resident_roofline(eng, args.workload, g, T, B, ms, copy_gbs)
             if not args.no_stream_leg:
-                # the HBM-bound engine (used for codes that do not fit LDS), same workload, for the record
+                # the HBM-bound engine (used for codes that do not fit LDS), same workload: the north_star's CN->VN sweep
                 os.environ["LDPC_ENGINE_MODE"] = "stream"
                 try:
                     eng_s, dec_s, _ = build_decoder(args.workload, device)
                 finally:
                     os.environ.pop("LDPC_ENGINE_MODE", None)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                eng_s.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
-                e0.record()
-                for _ in range(3):
-                    eng_s.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
-                e1.record()
-                e1.synchronize()
-                out["stream_engine"] = {"ms_per_step": e0.elapsed_time(e1) / 3,
-                                        "value": B / (e0.elapsed_time(e1) / 3 * 1e-3), "roofline": stream_roofline(eng_s)}
+                run_s = lambda: eng_s.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
+                run_s()
+                ms_s = event_ms(run_s, 3, torch)
+                out["stream_engine"] = {"ms_per_step": ms_s, "value": B / (ms_s * 1e-3), "engine": eng_s.info(),
+                                        "roofline": stream_roofline(eng_s, args.workload, g, T, B, llr, reps, copy_gbs, torch)}
                 del eng_s, dec_s
         else:
-            out["roofline"] = stream_roofline(eng)
-        out["decode_algorithmic_GBps"] = per_cw_decode * B / (ms_per_step * 1e-3) / 1e9
+            out["roofline"] = stream_roofline(eng, args.workload, g, T, B, llr, reps, copy_gbs, torch)
+        out["decode_algorithmic_GBps"] = bm["decode"] / (ms_per_step * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)
+        if world == 1 and not use_dist and not args.no_legs and args.workload == "basic" and not args.batch and not early:
+            # the other BASELINE configs, bounded (a few steps each), so that one driver run carries every config
+            del llr, res
+            torch.cuda.empty_cache()
+            out["workloads"] = {}
+            for w in LEGS:
+                out["workloads"][w] = measure_leg(w, device, args.snr_db, max(args.leg_steps, 1), reps, copy_gbs,
+                                                  not args.no_cpu_baseline, torch)
         sys.stdout.flush()
         os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)

@@ -22,10 +22,11 @@ LIB_NAME = "libldpc_hip.so"
 LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # override: A/B kernel variants
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip.h")
+DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip_debug.h")
 
 LDPC_F32, LDPC_F64 = 0, 1
 C2V_NMS, C2V_RCQ, C2V_OMS = 0, 1, 2
-MODE_AUTO, MODE_STREAM, MODE_RESIDENT = 0, 1, 2
+MODE_AUTO, MODE_STREAM, MODE_RESIDENT, MODE_SWEEPS = 0, 1, 2, 3
 SCHED_FLOODING, SCHED_LAYERED_REF = 0, 1
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -41,7 +42,7 @@ def build_native(force: bool = False, verbose: bool = False, defines=(), out: Op
     """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir.
     `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
     srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"),
-            os.path.join(CSRC, "ldpc_resident.hip"), os.path.join(CSRC, "ldpc_train.hip"), HEADER]
+            os.path.join(CSRC, "ldpc_resident.hip"), os.path.join(CSRC, "ldpc_train.hip"), HEADER, DEBUG_HEADER]
     target = out or os.path.join(_HERE, LIB_NAME)
     if not force and os.path.exists(target) and all(
             os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
@@ -67,12 +68,15 @@ class DecoderDesc(C.Structure):
                 ("schedule", C.c_int32)]
 
 
-# every symbol include/ldpc_hip.h declares (tests check the library exports them all)
-EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
-           "ldpc_decoder_set_mode", "ldpc_decoder_info",
-           "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
-           "ldpc_decode", "ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_last_error", "ldpc_abi_version",
-           "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
+# every symbol include/ldpc_hip.h declares (tests check the library exports them all) ...
+PRODUCT_EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
+                   "ldpc_decoder_set_mode", "ldpc_decoder_info",
+                   "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
+                   "ldpc_decode", "ldpc_last_error", "ldpc_abi_version",
+                   "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
+# ... and the measurement / test hooks of include/ldpc_hip_debug.h (bench.py's per-kernel timing, the tests' state dumps)
+DEBUG_EXPORTS = ("ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_debug_resident_c2v")
+EXPORTS = PRODUCT_EXPORTS + DEBUG_EXPORTS
 
 _lib = None
 _lock = threading.Lock()
@@ -119,6 +123,8 @@ def load():
         lib.ldpc_debug_sweep.argtypes = [vp, i64, i32, i32, vp, C.c_size_t, vp]
         lib.ldpc_debug_workspace_layout.restype = C.c_int
         lib.ldpc_debug_workspace_layout.argtypes = [vp, i64, vp]
+        lib.ldpc_debug_resident_c2v.restype = C.c_int
+        lib.ldpc_debug_resident_c2v.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
         lib.ldpc_train_saved_bytes.restype = C.c_size_t
         lib.ldpc_train_saved_bytes.argtypes = [vp, i64]
         lib.ldpc_train_workspace_bytes.restype = C.c_size_t

@@ -5,8 +5,10 @@ differentiable torch operations on ``nn.Parameter``s (neural_2d_decoder.py:133-2
 training_framework.py:127-134 and :322-324).
 
 The weight tables are assembled from the ``ParameterDict`` entries with differentiable torch
-operations (``cat`` / ``index_put``), so autograd itself routes the table gradients the HIP backward
-sweeps return (include/ldpc_hip.h: ldpc_decode_saving / ldpc_backward) to the individual parameters.
+operations (``cat`` / ``index_put``) and handed to the registered operator
+``torch.ops.ldpc.minsum_decode_train`` (torch_ops.py), so autograd itself routes the table gradients
+the HIP backward sweeps return (include/ldpc_hip.h: ldpc_decode_saving / ldpc_backward) to the
+individual parameters.
 Parameters that do not influence the returned posterior get a zero gradient (the reference leaves
 ``.grad`` at None for them).
 
@@ -27,7 +29,6 @@ logger = logging.getLogger(__name__)
 # return a posterior without grad_fn (and say so once) instead of exhausting HBM
 MAX_SAVED_BYTES = int(os.environ.get("LDPC_TRAIN_MAX_SAVED_BYTES", str(8 << 30)))
 _warned = False
-RECYCLE_SAVED = True        # release the saved messages to the engine's spare slot after backward (see backward())
 
 
 def wants_grad(module: torch.nn.Module, llr=None) -> bool:
@@ -52,64 +53,22 @@ def saved_state_fits(engine, batch: int) -> bool:
     return False
 
 
-class MinSumDecodeFn(torch.autograd.Function):
-    """(beta_table [T, Sb], alpha_table [T, Sa]) -> posterior [B, n]; bits and iterations ride along.
+def decode_train(beta_table: torch.Tensor, alpha_table: torch.Tensor, engine, x: torch.Tensor, early_stop: bool,
+                 alpha_is_oms: bool = False):
+    """(beta_table [T, Sb], alpha_table [T, Sa], llr x [B, n]) -> (posterior [B, n], bits, iterations) through the
+    registered operator ``torch.ops.ldpc.minsum_decode_train`` (torch_ops.py): its autograd formula runs the HIP
+    backward sweeps (``torch.ops.ldpc.minsum_backward``) and returns d loss/d beta, d loss/d alpha and -- when `x`
+    requires grad (a trainable front end feeding the decoder) -- d loss/d llr from the same sweep.
     `alpha_is_oms`: the alpha table is the check-side offset of the offset decoders (engine slot oms_alpha),
     otherwise the variable-side multiplier (engine slot alpha)."""
-
-    @staticmethod
-    def forward(ctx, beta_table, alpha_table, engine, xd, early_stop, alpha_is_oms=False, llr_in=None):
-        """xd: the LLRs as the engine takes them (detached, fp32, on the GPU); llr_in: the caller's own tensor when it
-        requires grad (a trainable front end feeding the decoder) -- its gradient is d loss/d llr from the same sweep"""
-        ctx.llr_meta = None
-        if llr_in is not None and llr_in.requires_grad:
-            ctx.llr_meta = (llr_in.device, llr_in.dtype, tuple(llr_in.shape))
-        res, saved = engine.decode_saving(xd, early_stop=early_stop)
-        ctx.engine, ctx.saved, ctx.xd, ctx.iters = engine, saved, xd, res.iterations
-        ctx.alpha_is_oms = bool(alpha_is_oms)
-        ctx.tables = (beta_table.detach().to("cpu", torch.float32).numpy().copy(),
-                      alpha_table.detach().to("cpu", torch.float32).numpy().copy())
-        ctx.meta = (beta_table.device, beta_table.dtype, alpha_table.device, alpha_table.dtype)
-        ctx.mark_non_differentiable(res.bits, res.iterations)
-        return res.posterior, res.bits, res.iterations
-
-    @staticmethod
-    def _upload(eng, beta, alpha, alpha_is_oms):
-        if alpha_is_oms:
-            eng.set_weights(beta, None, alpha if eng.current_tables()[2] is not None else None)
-        else:
-            eng.set_weights(beta, alpha)
-
-    @staticmethod
-    def backward(ctx, g_post, _g_bits, _g_iters):
-        eng = ctx.engine
-        if ctx.saved is None:
-            raise RuntimeError("the saved messages of this decode were released by its first backward; for "
-                               "backward(retain_graph=True) set autograd_bridge.RECYCLE_SAVED = False")
-        held = eng.current_tables()
-        held_alpha = held[2] if ctx.alpha_is_oms else held[1]
-        same = np.array_equal(held[0], ctx.tables[0]) and (held_alpha is None or np.array_equal(held_alpha, ctx.tables[1]))
-        if not same:                       # the weights moved on since this forward: put its tables back for the sweep
-            MinSumDecodeFn._upload(eng, ctx.tables[0], ctx.tables[1], ctx.alpha_is_oms)
-        gl = None
-        try:
-            if ctx.llr_meta is not None:
-                gb, ga, goa, gl = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post, want_grad_llr=True)
-            else:
-                gb, ga, goa = eng.backward(ctx.saved, ctx.xd, ctx.iters, g_post)
-        finally:
-            if not same:
-                MinSumDecodeFn._upload(eng, held[0], held_alpha, ctx.alpha_is_oms)
-        if RECYCLE_SAVED:                  # GBs of messages: hand the buffer to the next forward instead of the allocator
-            eng.recycle_saved(ctx.saved)
-            ctx.saved = None
-        if ctx.alpha_is_oms:
-            ga = goa if goa is not None else torch.zeros(ctx.tables[1].shape, dtype=torch.float32, device=gb.device)
-        bdev, bdt, adev, adt = ctx.meta
-        if gl is not None:
-            ldev, ldt, lshape = ctx.llr_meta
-            gl = gl.to(device=ldev, dtype=ldt).reshape(lshape)
-        return gb.to(device=bdev, dtype=bdt), ga.to(device=adev, dtype=adt), None, None, None, None, gl
+    import torch_ops
+    xd = x.to(device=engine.device, dtype=torch.float32)       # differentiable: the LLR gradient flows back through it
+    if not x.requires_grad:
+        xd = xd.detach()
+    post, bits, iters, _saved = torch.ops.ldpc.minsum_decode_train(xd.contiguous(), beta_table, alpha_table,
+                                                                  torch_ops.engine_handle(engine), bool(early_stop),
+                                                                  bool(alpha_is_oms))
+    return post, bits, iters
 
 
 def table_from_params(params, where, shape, default: float) -> torch.Tensor:

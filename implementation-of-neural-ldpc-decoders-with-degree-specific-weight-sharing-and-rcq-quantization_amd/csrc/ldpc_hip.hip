@@ -8,6 +8,8 @@
 #include "ldpc_train.hip"
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ldpc_hip.h"
+#include "../../include/ldpc_hip_debug.h"
 
 using namespace ldpc;
 
@@ -97,9 +100,18 @@ struct ldpc_decoder {
     size_t res_lds = 0;
     ResidentPlan res{};
     std::vector<void *> res_bufs;  // device allocations owned by the plan
+    // fused RCQ iteration of the streaming engine (cn_gather): per-edge gather metadata, built at creation for fp32
+    // flooding RCQ decoders on graphs with variable degree <= 8
+    bool gat_ok = false;
+    int4 *gat_meta = nullptr;      // [E + 1]
+    int *gat_nbr = nullptr;        // [sum dv(dv-1) + 8]
 };
 
 namespace {
+
+bool use_resident(const ldpc_decoder *d) { return d->res_ok && d->mode != LDPC_MODE_STREAM && d->mode != LDPC_MODE_SWEEPS; }
+// streaming engine, RCQ: one fused kernel per iteration (cn_gather) unless the two-sweep form is forced
+bool use_gather(const ldpc_decoder *d) { return d->gat_ok && d->mode != LDPC_MODE_SWEEPS; }
 
 // tile width: 64 lanes x VEC codewords.  fp32: VEC 4 (16 B per lane) for real batches,
 // VEC 1 for latency-mode batches <= 64; fp64: VEC 2 / 1.
@@ -135,7 +147,7 @@ Workspace carve(const ldpc_decoder *d, int64_t batch, void *base)
         return o;
     };
     const size_t o_llr = take(tw * n * es);
-    const size_t o_v2c = take(tw * std::max<size_t>(E, 1) * es);
+    const size_t o_v2c = take(tw * std::max<size_t>(E, 1) * (use_gather(d) ? 1 : es));   // gather form: the second code buffer
     const size_t o_c2v = take(tw * std::max<size_t>(E, 1) * (d->form == LDPC_C2V_RCQ ? 1 : es));
     const size_t o_post = take(tw * n * es);
     const size_t o_bits = take((size_t)w.tiles * n * w.vec * sizeof(uint64_t));
@@ -205,7 +217,8 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
 }
 
 template <typename T, int VEC>
-int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool use_done, hipStream_t s)
+int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool use_done, hipStream_t s,
+              bool store_posterior = true)
 {
     const GraphDev g = d->g->dev();
     const int vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -222,7 +235,7 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
     hipLaunchKernelGGL((vn_sweep<T, VEC, CODES, LAST>), grid, block, shmem, s, g, (const void *)w.c2v,  \
                        (const T *)w.llrT, (T *)w.v2c, alpha_row, d->alpha_slot, (const float *)d->lut,  \
                        lut_total, lut_cur, lut_stride, (const int *)d->q_of_iter_dev,                   \
-                       (const int *)w.iters, w.bitsT, (T *)w.postT, done, vb)
+                       (const int *)w.iters, w.bitsT, store_posterior ? (T *)w.postT : (T *)nullptr, done, vb)
     if (codes) {
         if constexpr (sizeof(T) == 4) {
             if (last) LDPC_VN(true, true); else LDPC_VN(true, false);
@@ -233,6 +246,45 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
         if (last) LDPC_VN(false, true); else LDPC_VN(false, false);
     }
 #undef LDPC_VN
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+// fused RCQ iteration `it` >= 1: codes of iteration it-1 (`cin`) -> codes of iteration it (`cout`)
+template <int VEC>
+int launch_gather(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, const char *cin, char *cout,
+                  hipStream_t s)
+{
+    const GraphDev g = d->g->dev();
+    const int cpw = (g.E < 8 * (long long)g.m) ? 2 : 1;
+    const int per_block = kWavesPerBlock * cpw;
+    const int cb = (g.m + per_block - 1) / per_block;
+    if (cb == 0 || g.E == 0) return LDPC_OK;
+    const dim3 grid((unsigned)((size_t)w.tiles * cb)), block(kBlock);
+    const float *beta_row = (const float *)d->beta + (size_t)it * d->n_beta;
+    const float *alpha_prev = (const float *)d->alpha + (size_t)(it - 1) * d->n_alpha;
+    const float *thr = d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels;
+    const int lut_stride = 2 * d->n_levels, lut_total = d->n_quant * lut_stride;
+    const int lut_prev = d->q_of_iter[it - 1] * lut_stride;
+    const size_t shmem = (size_t)lut_total * sizeof(float);
+    const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_GA(NL_, BPC_, CPW_)                                                                                     \
+    hipLaunchKernelGGL((cn_gather<VEC, NL_, BPC_, CPW_>), grid, block, shmem, s, g, (const int4 *)d->gat_meta,        \
+                       (const int *)d->gat_nbr, (const float *)w.llrT, (const uint8_t *)cin, (uint8_t *)cout, beta_row, \
+                       (const int *)d->beta_slot, alpha_prev, thr, d->n_levels, (const float *)d->lut, lut_total,      \
+                       lut_prev, done, cb)
+    const int variant = (d->n_levels == 4 ? 4 : 0) + (d->beta_per_check ? 2 : 0) + (cpw == 2 ? 1 : 0);
+    switch (variant) {
+    case 0: LDPC_GA(0, false, 1); break;
+    case 1: LDPC_GA(0, false, 2); break;
+    case 2: LDPC_GA(0, true, 1); break;
+    case 3: LDPC_GA(0, true, 2); break;
+    case 4: LDPC_GA(4, false, 1); break;
+    case 5: LDPC_GA(4, false, 2); break;
+    case 6: LDPC_GA(4, true, 1); break;
+    default: LDPC_GA(4, true, 2); break;
+    }
+#undef LDPC_GA
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }
@@ -304,6 +356,34 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         int rc = launch_vn<T, VEC>(d, w, 0, /*last=*/true, /*use_done=*/false, s);
         if (rc) return rc;
     }
+    if (use_gather(d) && !saved) {
+        if constexpr (sizeof(T) == 4) {
+            // RCQ, fused form: iteration 0 is the plain check sweep on the LLRs, every later iteration ONE cn_gather
+            // launch (codes ping-pong between the two code buffers; iteration `it` writes buffer it & 1).  The hard
+            // decisions the stop rule needs come from a posterior-only variable pass per iteration (early stop), or
+            // once at the end (fixed T).
+            char *buf[2] = {w.c2v, w.v2c};
+            for (int it = 0; it < T_it; ++it) {
+                int rc;
+                if (it == 0) {
+                    rc = launch_cn<T, VEC>(d, w, 0, early_stop, s);
+                } else {
+                    rc = launch_gather<VEC>(d, w, it, early_stop, buf[(it - 1) & 1], buf[it & 1], s);
+                }
+                if (rc) return rc;
+                const bool last = it == T_it - 1;
+                if (early_stop || last) {
+                    Workspace wv = w;
+                    wv.c2v = buf[it & 1];
+                    rc = launch_vn<T, VEC>(d, wv, it, /*last=*/true, early_stop, s, /*store_posterior=*/last);
+                    if (rc) return rc;
+                }
+                if (early_stop)
+                    hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
+                                       w.iters, it + 1, 1);
+            }
+        }
+    } else
     for (int it = 0; it < T_it; ++it) {
         // training forward: iteration `it` writes its c2v rows, and the v2c rows the next one reads, straight into
         // their slices of `saved` (SavedLayout).  A stopped codeword's rows stay latched because the check sweep
@@ -464,8 +544,10 @@ struct LaneCost {
 void optimise_lane_order(std::vector<int> &order, const std::vector<std::vector<int>> &vs, int G)
 {
     if (G != 1 && G != 2) return;
+#ifdef LDPC_RESIDENT_PROBES                         // tuning builds only (tools/): the product library reads no environment
     const char *off = getenv("LDPC_RESIDENT_NO_LANE_OPT");
     if (off && atoi(off)) return;
+#endif
     LaneCost lc{vs, order, 32, 32, G == 2 ? 16 : 32, G == 2 ? 16 : 32};
     const int n = (int)order.size();
     std::vector<std::pair<int, int>> classes;
@@ -508,13 +590,15 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     // the other's phase -- measured best on the (1998,1512) code; larger codes fall back to one workgroup
     // per CU or G = 1.  A row stride of 512 slots (instead of m) lets LDS instructions carry t*stride as an
     // immediate offset; it is taken when it costs neither G nor workgroups per CU.
-    // LDPC_RESIDENT_G / _NT override for tuning.
+    // LDPC_RESIDENT_G / _NT override for tuning (read only by -DLDPC_RESIDENT_PROBES builds).
     auto geometry = [&](int stride, int &G_out, int &blocks_out) {
         const long long S_ = (long long)g->max_dc * stride;
         if (S_ > 65535 || !resident_fits(d, S_, 1, 1)) return false;
         int G_ = 0;
+#ifdef LDPC_RESIDENT_PROBES
         const char *eg = getenv("LDPC_RESIDENT_G");
         if (eg) G_ = atoi(eg);
+#endif
         if (!((G_ == 1 || G_ == 2) && resident_fits(d, S_, G_, 1))) G_ = resident_fits(d, S_, 2, 1) ? 2 : 1;
         int b_ = 1;
         while (b_ < 8 && resident_fits(d, S_, G_, b_ + 1)) ++b_;
@@ -530,7 +614,9 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     }
     const long long S = (long long)g->max_dc * mstride;
     int NT = 0;
+#ifdef LDPC_RESIDENT_PROBES
     { const char *en = getenv("LDPC_RESIDENT_NT"); if (en) NT = atoi(en); }
+#endif
     if (NT < 64 || NT > 1024 || NT % 64) NT = blocks >= 2 ? 512 : 1024;
 
     std::vector<int> perm_c(m), perm_v(n), pos_c(m), pos_v(n);
@@ -557,6 +643,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     std::vector<uint32_t> vmeta(n);
     std::vector<uint4> vslot_lo(n), vslot_hi(n);
     std::vector<int> slot_of_edge(g->E);
+    std::vector<uint32_t> edge_of_slot((size_t)S, 0xffffffffu);
     bool per_check = true;
     for (int p = 0; p < m; ++p) {
         const int i = perm_c[p], e0 = g->h_check_ptr[i], dc = dc_of(i);
@@ -564,6 +651,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
         for (int t = 0; t < dc; ++t) {
             const int e = e0 + t, slot = t * mstride + p;
             slot_of_edge[e] = slot;
+            edge_of_slot[slot] = (uint32_t)e;
             cvar[slot] = (uint16_t)pos_v[g->h_var_idx[e]];
             bslot[slot] = (uint16_t)desc->beta_slot[e];
             if (desc->beta_slot[e] != desc->beta_slot[e0]) per_check = false;
@@ -582,7 +670,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     }
     ResidentPlan &pl = d->res;
     pl = ResidentPlan{};
-    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv; pl.mstride = mstride;
+    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv; pl.mstride = mstride; pl.E = g->E;
     int rc = plan_upload(d, &pl.dc_s, dc_s);
     if (!rc) rc = plan_upload(d, &pl.cvar, cvar);
     if (!rc) rc = plan_upload(d, &pl.bslot, bslot);
@@ -592,10 +680,25 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     if (!rc) rc = plan_upload(d, &pl.vslot_lo, vslot_lo);
     if (!rc) rc = plan_upload(d, &pl.vslot_hi, vslot_hi);
     if (!rc) rc = plan_upload(d, &pl.inv_perm_v, inv);
+    if (!rc) rc = plan_upload(d, &pl.edge_of_slot, edge_of_slot);
     if (rc) return rc;
     d->res_G = G; d->res_NT = NT;
     d->res_lds = res_lds_total((int)S, n, G, resident_alpha_floats(d));
     d->res_ok = true;
+    return LDPC_OK;
+}
+
+// A kernel's dynamic-LDS ceiling is process-wide state of that kernel on a device: it is raised ONCE per
+// instantiation and device to the full 160 KiB (not per launch, and not to one decoder's size -- another decoder
+// of a larger code launches the same instantiation).
+int allow_full_lds(const void *kfn, int device)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kfn, device})) return LDPC_OK;
+    HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    done.insert({kfn, device});
     return LDPC_OK;
 }
 
@@ -610,7 +713,7 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
     do {                                                                                                  \
         auto kfn = a.early_stop ? resident_decode<1, FORM_NMS, true, 0, MS, 1, double>                    \
                                 : resident_decode<1, FORM_NMS, true, 0, MS, 0, double>;                   \
-        HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                      \
         hipLaunchKernelGGL(kfn, dim3(blocks64), dim3(d->res_NT), lds, s, d->res, a);                      \
     } while (0)
         if (d->res.mstride == 512) LDPC_RES64(512); else LDPC_RES64(0);
@@ -619,12 +722,14 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
         return LDPC_OK;
     }
     const unsigned blocks = (unsigned)((a.batch + G - 1) / G);
+#ifdef LDPC_RESIDENT_PROBES
     { const char *pad = getenv("LDPC_RES_LDS_PAD"); if (pad && atoi(pad) > 0) lds = std::min<size_t>(lds + atoi(pad), 160 * 1024); }  // occupancy experiments
+#endif
 #define LDPC_RES_MS(FORM, NL, MS)                                                                        \
     do {                                                                                                 \
         auto kfn = d->res.bslot_c ? (a.early_stop ? resident_decode<G, FORM, true, NL, MS, 1> : resident_decode<G, FORM, true, NL, MS, 0>)   \
                                   : (a.early_stop ? resident_decode<G, FORM, false, NL, MS, 1> : resident_decode<G, FORM, false, NL, MS, 0>); \
-        HIP_TRY(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                     \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
     } while (0)
 #define LDPC_RES(FORM, NL)                                                                               \
@@ -641,7 +746,31 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
     return LDPC_OK;
 }
 
-bool use_resident(const ldpc_decoder *d) { return d->res_ok && d->mode != LDPC_MODE_STREAM; }
+int decode_resident(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop, int32_t *bits,
+                    void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed_bits, void *dbg_c2v,
+                    void *stream)
+{
+    DeviceGuard guard(d->g->device);
+    ResidentArgs a{};
+    a.llr = (const float *)llr; a.batch = batch; a.T = d->T; a.early_stop = early_stop != 0;
+    a.beta = (const float *)d->beta; a.n_beta = d->n_beta;
+    a.alpha = (const float *)d->alpha; a.n_alpha = d->n_alpha;
+    a.oms_alpha = (const float *)d->oms_alpha; a.n_oms_alpha = d->n_oms_alpha;
+    a.thr = d->thresholds; a.n_levels = d->n_levels; a.q_of_iter = d->q_of_iter_dev;
+    a.bits = bits; a.posterior = (float *)posterior; a.iterations = iterations; a.success = success;
+    a.packed = packed_bits;
+    a.dbg_c2v = dbg_c2v;
+#ifdef LDPC_RESIDENT_PROBES                          // phase-timing probes of tools/resident_probe*.sh; never in the product build
+    { const char *dbg = getenv("LDPC_RES_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
+#endif
+    a.alpha_in_lds = resident_alpha_floats(d) > 0;
+    a.unit_alpha = d->unit_alpha; a.rcq_zero0 = d->rcq_zero0;
+    hipStream_t rs = (hipStream_t)stream;
+    switch (d->res_G) {
+    case 1: return launch_resident<1>(d, a, rs);
+    default: return launch_resident<2>(d, a, rs);
+    }
+}
 
 }  // namespace
 
@@ -828,6 +957,25 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
         rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
         if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
     }
+    if (!rc && d->form == LDPC_C2V_RCQ && d->dtype == LDPC_F32 && d->schedule == LDPC_SCHED_FLOODING &&
+        g->E > 0 && g->max_dv <= 8) {
+        // gather metadata of the fused RCQ iteration (cn_gather): per CSR edge its variable, where the list of
+        // the variable's OTHER edges starts (ascending check order = CSC order), how many there are, alpha column
+        std::vector<int4> meta((size_t)g->E + 1);
+        std::vector<int> nbr;
+        nbr.reserve((size_t)g->E * 3 + 8);
+        for (int e = 0; e < g->E; ++e) {
+            const int j = g->h_var_idx[e], s0 = g->h_var_ptr[j], dv = g->h_var_ptr[j + 1] - s0;
+            meta[e] = make_int4(j, (int)nbr.size(), dv - 1, desc->alpha_slot[j]);
+            for (int k = 0; k < dv; ++k)
+                if (g->h_csc[s0 + k] != e) nbr.push_back(g->h_csc[s0 + k]);
+        }
+        meta[g->E] = make_int4(0, 0, 0, 0);           // what the prefetch past the last edge of the last check reads
+        nbr.resize(nbr.size() + 8, 0);
+        rc = upload(&d->gat_meta, meta.data(), meta.size());
+        if (!rc) rc = upload(&d->gat_nbr, nbr.data(), nbr.size());
+        d->gat_ok = !rc;
+    }
     resident_table_flags(d, desc->alpha, d->form == LDPC_C2V_RCQ ? desc->thresholds : nullptr);
     if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
     if (rc) {
@@ -846,7 +994,7 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
 int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
 {
     if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
-    if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_RESIDENT) return fail(LDPC_ERR_ARG, "bad mode");
+    if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_SWEEPS) return fail(LDPC_ERR_ARG, "bad mode");
     if (mode == LDPC_MODE_RESIDENT && !d->res_ok)
         return fail(LDPC_ERR_UNSUPPORTED, "code does not qualify for the LDS-resident engine "
                                           "(fp32, dc <= 32, dv <= 8, state within 160 KiB of LDS)");
@@ -857,7 +1005,7 @@ int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
 int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4])
 {
     if (!d || !out4) return fail(LDPC_ERR_ARG, "NULL argument");
-    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : LDPC_MODE_STREAM;
+    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : (use_gather(d) ? LDPC_MODE_STREAM : LDPC_MODE_SWEEPS);
     out4[1] = d->res_ok ? (d->dtype == LDPC_F64 ? 1 : d->res_G) : 0;      // fp64: one codeword in a float pair's slots
     out4[2] = d->res_ok ? d->res_NT : 0;
     out4[3] = d->res_ok ? (int32_t)d->res_lds : 0;
@@ -892,6 +1040,7 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipFree(d->beta_slot); (void)hipFree(d->alpha_slot); (void)hipFree(d->oms_alpha_slot);
     (void)hipFree(d->thresholds); (void)hipFree(d->lut); (void)hipFree(d->q_of_iter_dev);
     for (void *p : d->res_bufs) (void)hipFree(p);
+    (void)hipFree(d->gat_meta); (void)hipFree(d->gat_nbr);
     delete d;
 }
 
@@ -912,25 +1061,8 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
     if (!llr || !workspace) return fail(LDPC_ERR_ARG, "NULL llr/workspace");
     if (d->g->n == 0) return LDPC_OK;
     if (((uintptr_t)workspace % kAlign) != 0) return fail(LDPC_ERR_ARG, "workspace must be %zu-byte aligned", kAlign);
-    if (use_resident(d)) {
-        DeviceGuard guard(d->g->device);
-        ResidentArgs a{};
-        a.llr = (const float *)llr; a.batch = batch; a.T = d->T; a.early_stop = early_stop != 0;
-        a.beta = (const float *)d->beta; a.n_beta = d->n_beta;
-        a.alpha = (const float *)d->alpha; a.n_alpha = d->n_alpha;
-        a.oms_alpha = (const float *)d->oms_alpha; a.n_oms_alpha = d->n_oms_alpha;
-        a.thr = d->thresholds; a.n_levels = d->n_levels; a.q_of_iter = d->q_of_iter_dev;
-        a.bits = bits; a.posterior = (float *)posterior; a.iterations = iterations; a.success = success;
-        a.packed = packed_bits;
-        { const char *dbg = getenv("LDPC_RES_DEBUG"); a.debug_skip = dbg ? atoi(dbg) : 0; }
-        a.alpha_in_lds = resident_alpha_floats(d) > 0;
-        a.unit_alpha = d->unit_alpha; a.rcq_zero0 = d->rcq_zero0;
-        hipStream_t rs = (hipStream_t)stream;
-        switch (d->res_G) {
-        case 1: return launch_resident<1>(d, a, rs);
-        default: return launch_resident<2>(d, a, rs);
-        }
-    }
+    if (use_resident(d))
+        return decode_resident(d, llr, batch, early_stop, bits, posterior, iterations, success, packed_bits, nullptr, stream);
     const Workspace w = carve(d, batch, workspace);
     if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
     if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -1129,9 +1261,20 @@ int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t ou
     char *base = reinterpret_cast<char *>(kAlign);   // any non-null base: only differences are used
     const Workspace w = carve(d, batch, base);
     out8[0] = w.vec; out8[1] = w.tiles;
-    out8[2] = w.llrT - base; out8[3] = w.v2c - base; out8[4] = w.c2v - base; out8[5] = w.postT - base;
+    // fused RCQ form: the codes ping-pong between the two buffers, iteration T-1 leaves them in buffer (T-1) & 1
+    const char *c2v_final = (use_gather(d) && d->T > 0 && ((d->T - 1) & 1)) ? w.v2c : w.c2v;
+    out8[2] = w.llrT - base; out8[3] = w.v2c - base; out8[4] = c2v_final - base; out8[5] = w.postT - base;
     out8[6] = (char *)w.bitsT - base; out8[7] = (char *)w.done - base;
     return LDPC_OK;
+}
+
+int ldpc_debug_resident_c2v(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop,
+                            void *posterior, int32_t *iterations, void *c2v_out, void *stream)
+{
+    if (!d || !llr || !posterior || !c2v_out || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
+    if (!use_resident(d)) return fail(LDPC_ERR_ARG, "the decoder is not on the LDS-resident engine");
+    if (d->g->n == 0) return LDPC_OK;
+    return decode_resident(d, llr, batch, early_stop, nullptr, posterior, iterations, nullptr, nullptr, c2v_out, stream);
 }
 
 int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_t iter, void *workspace,
@@ -1145,6 +1288,19 @@ int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_
     DeviceGuard guard(d->g->device);
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = d->dtype == LDPC_F64;
+    if (use_gather(d) && !f64) {
+        // fused RCQ form: which = 0 is the fused iteration kernel (iter >= 1; iteration 0 is the plain check sweep),
+        // which = 1 the posterior-only variable pass
+        char *buf[2] = {w.c2v, w.v2c};
+        if (which == 0 && iter >= 1)
+            return w.vec == 1 ? launch_gather<1>(d, w, iter, false, buf[(iter - 1) & 1], buf[iter & 1], s)
+                              : launch_gather<4>(d, w, iter, false, buf[(iter - 1) & 1], buf[iter & 1], s);
+        if (which != 0) {
+            Workspace wv = w;
+            wv.c2v = buf[iter & 1];
+            return w.vec == 1 ? launch_vn<float, 1>(d, wv, iter, true, false, s) : launch_vn<float, 4>(d, wv, iter, true, false, s);
+        }
+    }
 #define LDPC_DBG(REAL_, V_)                                                                 \
     return which == 0 ? launch_cn<REAL_, V_>(d, w, iter, false, s)                           \
                       : launch_vn<REAL_, V_>(d, w, iter, iter == d->T - 1, false, s)

@@ -548,7 +548,9 @@ __device__ __forceinline__ void vn_body(const GraphDev &g, int tile, int j, int 
         uint64_t mask = __ballot(post.x[c] < (T)0);
         if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
     }
-    if constexpr (LAST) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);
+    if constexpr (LAST) {
+        if (postT) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);   // null: hard decisions only
+    }
 }
 
 template <typename T, int VEC, bool CODES, int ORDER, bool LAST>
@@ -583,7 +585,7 @@ __device__ __forceinline__ void vn_generic(const GraphDev &g, int tile, int j, i
         uint64_t mask = __ballot(post.x[c] < (T)0);
         if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
     }
-    if (LAST) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);
+    if (LAST && postT) st<T, VEC>(postT + ((size_t)tile * g.n + j) * W + lane_off, post);
 }
 
 template <typename T, int VEC, bool CODES, bool LAST>
@@ -636,6 +638,206 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
         vn_generic<T, VEC, CODES, ORDER, LAST>(g, tile, j, s0, dv, lane, c2v, llrT, v2c, a, lut, bitsT, postT, fz);
     }
 #undef LDPC_VN_CASE
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused RCQ iteration ("gather" form): ONE kernel per iteration, no V2C array at all.
+//
+// With 1-byte C2V codes the variable->check messages are cheaper to RECOMPUTE than to store: the check sweep of
+// iteration t needs, for its edge (i, j),   v2c = llr[j] + alpha_{t-1} * sum_{i' != i} deq_{t-1}(code_{t-1}[i', j])
+// (rcq_decoder.py:257 / :575), i.e. the LLR row of j and the dv(j)-1 code rows of j's OTHER edges -- 4 + (dv-1)
+// bytes per edge and codeword instead of writing and re-reading a 4-byte V2C value, and the variable sweep
+// disappears from the iteration.  Per codeword and iteration the kernel issues 4E + sum_j dv(dv-1) bytes of reads
+// (345 KB on the (16200,7200) code, most of them cache hits: the distinct bytes are 4n + E) and writes E code
+// bytes, against 10E + 4n = 551 KB in HBM for the two-sweep form.  Codes are double-buffered (every check
+// reads the previous iteration's codes of its neighbours' other edges).
+//
+// Same wave mapping as cn_sweep (wave = one check x W codewords, every index wave-uniform); per-edge gather
+// metadata is precomputed by the host: meta[e] = {variable, offset into nbr, dv-1, alpha column}, nbr[] = CSR
+// edge ids of the variable's other edges in ascending check order (the reference's summation order).
+// The next edge's metadata, neighbour ids and LLR row are fetched while the current edge is processed.
+// ------------------------------------------------------------------------------------------
+//   gat_meta [E + 1]              (one padding entry: the prefetch of "the edge after the last" stays in bounds)
+//   gat_nbr  [sum_j dv(dv-1) + 8] (padded: eight ids are always fetched)
+
+template <int VEC, int CNT>
+__device__ __forceinline__ Pack<float, VEC> gather_v2c(const uint8_t *__restrict__ codes, const int (&nb)[8],
+                                                       const Pack<float, VEC> &l, float a, const Lut<VEC> &lut)
+{
+    constexpr int W = kWave * VEC;
+    Pack<uint8_t, VEC> q[CNT > 0 ? CNT : 1];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) q[k] = ld<uint8_t, VEC>(codes + (size_t)nb[k] * W);
+    Pack<float, VEC> out;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        float xs[CNT > 0 ? CNT : 1];
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) xs[k] = lut.base[lut.off[c] + q[k].x[c]];
+        out.x[c] = l.x[c] + a * sum_ct<CNT, -1, 0, float>(xs);      // same expression as vn_body (alpha * 0 for dv = 1)
+    }
+    return out;
+}
+
+template <int VEC, int NL, bool BPC, int CPW>
+__global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__restrict__ gat_meta,
+                                                    const int *__restrict__ gat_nbr, const float *__restrict__ llrT,
+                                                    const uint8_t *__restrict__ codes_in,
+                                                    uint8_t *__restrict__ codes_out,
+                                                    const float *__restrict__ beta_row,
+                                                    const int *__restrict__ beta_slot,
+                                                    const float *__restrict__ alpha_prev_row,
+                                                    const float *__restrict__ thr, int n_levels,
+                                                    const float *__restrict__ lut_global, int lut_total,
+                                                    int lut_prev_off, const uint64_t *__restrict__ done,
+                                                    int check_blocks)
+{
+    constexpr int W = kWave * VEC;
+    extern __shared__ float gather_lut_s[];
+    for (int k = threadIdx.x; k < lut_total; k += kBlock) gather_lut_s[k] = lut_global[k];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / check_blocks);
+    const int ibase = uni(((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
+    if (ibase >= g.m) return;
+
+    Frozen<VEC> fz;
+    const bool all_frozen = load_frozen<VEC>(done, tile, lane, fz);
+    float th[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
+    Lut<VEC> lut;
+    lut.base = gather_lut_s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) lut.off[c] = lut_prev_off;       // frozen codewords: their stores are masked anyway
+    const size_t lane_off = (size_t)lane * VEC;
+    const float *llr_tile = llrT + (size_t)tile * g.n * W + lane_off;
+    const uint8_t *cin_tile = codes_in + (size_t)tile * g.E * W + lane_off;
+    uint8_t *cout_tile = codes_out + (size_t)tile * g.E * W + lane_off;
+
+#pragma unroll
+    for (int cc_ = 0; cc_ < CPW; ++cc_) {
+    const int i = ibase + cc_;
+    if (i >= g.m) break;
+    const int e0 = uni(g.check_ptr[i]);
+    const int dc = uni(g.check_ptr[i + 1]) - e0;
+    if (dc == 0) continue;
+    if (all_frozen) {                              // the codes are double-buffered: carry the tile's latched rows over
+        for (int t = 0; t < dc; ++t)
+            st<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W, ld<uint8_t, VEC>(cin_tile + (size_t)(e0 + t) * W));
+        continue;
+    }
+
+    // one edge's variable->check message, recomputed from the previous iteration's codes
+    struct Edge { int4 md; int nb[8]; Pack<float, VEC> l; };
+    auto fetch = [&](int e, Edge &x) {
+        x.md = gat_meta[e];
+        const int *np = gat_nbr + x.md.y;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x.nb[k] = np[k];               // padded lists: reading 8 is always in bounds
+        x.l = ld<float, VEC>(llr_tile + (size_t)x.md.x * W);
+    };
+    auto value = [&](const Edge &x) -> Pack<float, VEC> {
+        const float a = alpha_prev_row[uni(x.md.w)];
+        int nb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nb[k] = uni(x.nb[k]);
+        switch (uni(x.md.z)) {
+        case 0: return gather_v2c<VEC, 0>(cin_tile, nb, x.l, a, lut);
+        case 1: return gather_v2c<VEC, 1>(cin_tile, nb, x.l, a, lut);
+        case 2: return gather_v2c<VEC, 2>(cin_tile, nb, x.l, a, lut);
+        case 3: return gather_v2c<VEC, 3>(cin_tile, nb, x.l, a, lut);
+        case 4: return gather_v2c<VEC, 4>(cin_tile, nb, x.l, a, lut);
+        case 5: return gather_v2c<VEC, 5>(cin_tile, nb, x.l, a, lut);
+        case 6: return gather_v2c<VEC, 6>(cin_tile, nb, x.l, a, lut);
+        default: return gather_v2c<VEC, 7>(cin_tile, nb, x.l, a, lut);    // host admits dv <= 8 to this kernel
+        }
+    };
+
+    float m1[VEC], m2[VEC];
+    int idx[VEC];
+    uint32_t sm[VEC];
+    unsigned par[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); idx[c] = 0; sm[c] = 0; par[c] = 0; }
+
+    Edge cur, nxt;
+    fetch(e0, cur);
+    for (int t = 0; t < dc; ++t) {
+        fetch(e0 + t + 1, nxt);                    // in flight across this edge's gather (meta is padded by one entry)
+        const Pack<float, VEC> v = value(cur);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const float a = __builtin_fabsf(v.x[c]);
+            const unsigned sb = signbit_of<float>(v.x[c]);
+            par[c] ^= sb;
+            sm[c] |= sb << (t & 31);
+            if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; idx[c] = t; }
+            else if (a < m2[c]) { m2[c] = a; }
+        }
+        cur = nxt;
+    }
+    if (dc == 1) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) m2[c] = m1[c];
+    }
+    const bool wide = dc > 32;                     // sign masks hold 32 edges; wider checks recompute their inputs
+
+    auto level = [&](float mag) {
+        int lvl = 0;
+        if constexpr (NL > 0) {
+#pragma unroll
+            for (int q = 1; q < NL; ++q) lvl = (mag >= th[q]) ? q : lvl;
+        } else if (n_levels <= 8) {
+#pragma unroll
+            for (int q = 1; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;
+        } else {
+            for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
+        }
+        return lvl;
+    };
+    unsigned cc1[VEC], cc2[VEC];
+    if constexpr (BPC) {                           // one beta per check: four candidate codes per codeword (see cn_sweep)
+        const float b = beta_row[beta_slot[e0]];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const float p1 = b * m1[c], p2 = b * m2[c];
+            const float a1 = __builtin_fabsf(p1), a2 = __builtin_fabsf(p2);
+            const unsigned l1 = (unsigned)level(a1), l2 = (unsigned)level(a2);
+            const unsigned s1 = signbit_of<float>(p1), s2 = signbit_of<float>(p2);
+            const unsigned z1 = a1 > 0.0f ? (unsigned)n_levels : 0u, z2 = a2 > 0.0f ? (unsigned)n_levels : 0u;
+            cc1[c] = (l1 + (s1 ? z1 : 0u)) | ((l1 + (s1 ? 0u : z1)) << 8);
+            cc2[c] = (l2 + (s2 ? z2 : 0u)) | ((l2 + (s2 ? 0u : z2)) << 8);
+        }
+    }
+    if (wide) fetch(e0, cur);
+    for (int t = 0; t < dc; ++t) {
+        Pack<float, VEC> re;
+        if (wide) {
+            fetch(e0 + t + 1, nxt);
+            re = value(cur);
+            cur = nxt;
+        }
+        Pack<uint8_t, VEC> o;
+        float b = 0.0f;
+        if constexpr (!BPC) b = beta_row[beta_slot[e0 + t]];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const unsigned own = wide ? signbit_of<float>(re.x[c]) : ((sm[c] >> (t & 31)) & 1u);
+            const unsigned neg = par[c] ^ own;
+            if constexpr (BPC) {
+                const unsigned cc = (t == idx[c]) ? cc2[c] : cc1[c];
+                o.x[c] = (uint8_t)((cc >> (neg * 8u)) & 0xffu);
+            } else {
+                const float raw = (t == idx[c]) ? m2[c] : m1[c];
+                const float w = flip_sign<float>(b * raw, neg);
+                const int lvl = level(__builtin_fabsf(w));
+                o.x[c] = (uint8_t)(((w < 0.0f) ? n_levels : 0) + lvl);                    // rcq_decoder.py:88-89
+            }
+        }
+        store_latched<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W, done ? cin_tile + (size_t)(e0 + t) * W : nullptr, o, fz);
+    }
+    }   // checks of this wave
 }
 
 // ------------------------------------------------------------------------------------------

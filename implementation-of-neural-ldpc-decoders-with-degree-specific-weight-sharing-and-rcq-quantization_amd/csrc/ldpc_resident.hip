@@ -47,6 +47,9 @@ struct ResidentPlan {
     const uint4 *vslot_lo;        // [n]          LDS byte offsets (= slot * G * 4) of edges k = 0..3 of q
     const uint4 *vslot_hi;        // [n]          ... of edges k = 4..7 (read only when max_dv > 4)
     const uint16_t *inv_perm_v;   // [n]          sorted position of original variable j
+    int E;                        // edges of the graph
+    const uint32_t *edge_of_slot; // [S]          CSR edge id held by a slot, 0xffffffff for padding slots (test hook
+                                  //              ldpc_debug_resident_c2v: dumps the C2V state in CSR order)
 };
 
 struct ResidentArgs {
@@ -62,6 +65,8 @@ struct ResidentArgs {
     int unit_alpha;               // every alpha == 1.0f (Basic, RCQ, sharing types 1/3): the multiply is skipped
     int rcq_zero0;                // every quantiser has tau_0 == 0 (true for gamma > 0): per-check quantisation
     int debug_skip;               // phase-timing probes, compiled in only with -DLDPC_RESIDENT_PROBES (tools/resident_probe*.sh)
+    void *dbg_c2v;                // [batch][E] or null: C2V values of every codeword's last executed iteration, CSR edge
+                                  // order (include/ldpc_hip_debug.h; lets the tests compare per-edge RCQ codes on this engine)
 };
 
 constexpr int kResAlphaMax = 1024;   // floats of alpha table kept in LDS
@@ -574,6 +579,23 @@ __device__ __forceinline__ void res_emit_bits(const ResidentPlan &pl, const Resi
     }
 }
 
+// test hook: C2V values sitting in the message slots -> dbg_c2v[b][e] for the codewords in `mask`
+template <int G, typename T>
+__device__ __forceinline__ void res_dump_c2v(const ResidentPlan &pl, const ResidentArgs &a, long long b0, unsigned mask,
+                                             int tid, int nt)
+{
+    using P = Pack<T, G>;
+    T *out = reinterpret_cast<T *>(a.dbg_c2v);
+    for (int s = tid; s < pl.S; s += nt) {
+        const unsigned e = pl.edge_of_slot[s];
+        if (e == 0xffffffffu) continue;
+        const P v = lds_load<P>((unsigned)s * (unsigned)sizeof(P));
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if ((mask >> g) & 1u) out[(size_t)(b0 + g) * pl.E + e] = v.x[g];
+    }
+}
+
 // LDS carve (bytes): msg at 0, then llr_s, alpha_s, bits_s, the syndrome word
 __host__ __device__ inline size_t res_off_llr(int S, int G) { return (size_t)S * G * 4; }
 __host__ __device__ inline size_t res_off_alpha(int S, int n, int G) { return res_off_llr(S, G) + (size_t)n * G * 4; }
@@ -723,6 +745,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             if (tid == 0) *sh_unsat = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
+                if (a.dbg_c2v) res_dump_c2v<G, T>(pl, a, b0, newly, tid, nt);      // slots still hold this iteration's C2V
                 res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, newly, tid, nt);
                 __syncthreads();
                 res_emit<G, T>(pl, a, llr_s, b0, newly, it + 1, 0u, tid, nt);
@@ -741,6 +764,14 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     // codewords still open after T iterations: outputs of the last iteration
     const unsigned open = ~done & kAll;
     if (!open) return;
+    if (a.dbg_c2v) {                                     // slots hold the C2V of iteration T-1 (zeros when T == 0)
+        unsigned real = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (b0 + g < a.batch) real |= 1u << g;
+        res_dump_c2v<G, T>(pl, a, b0, open & real, tid, nt);
+        __syncthreads();                                 // the final posterior pass overwrites the slots
+    }
     if (ES && !a.posterior && a.T > 0) {                 // bits_s hold iteration T's decisions already
         res_emit_bits<G>(pl, a, bits_s, b0, open, a.T, kAll, tid, nt);
         return;

@@ -135,7 +135,11 @@ class DecodeEngine:
         with torch.cuda.device(self.device):
             nat.check(lib.ldpc_decoder_create(C.byref(self.handle), self._ng.handle, C.byref(desc)),
                       "ldpc_decoder_create")
-        self._ws: Optional[torch.Tensor] = None
+        # scratch of ldpc_decode, one buffer PER STREAM: the C ABI wants one workspace per decode that may overlap
+        # another on the device, and calls from different threads arrive on different (or the same) torch streams --
+        # same stream = serialised by the stream, different streams = different buffers.  Guarded by _ws_lock.
+        self._ws = {}
+        self._ws_lock = threading.Lock()
         self.set_mode(os.environ.get("LDPC_ENGINE_MODE", "auto"))
 
     def __del__(self):
@@ -147,19 +151,23 @@ class DecodeEngine:
             pass
 
     # ------------------------------------------------------------------ engine choice
-    _MODES = {"auto": nat.MODE_AUTO, "stream": nat.MODE_STREAM, "resident": nat.MODE_RESIDENT}
+    _MODES = {"auto": nat.MODE_AUTO, "stream": nat.MODE_STREAM, "resident": nat.MODE_RESIDENT, "sweeps": nat.MODE_SWEEPS}
 
     def set_mode(self, mode: str):
-        """'auto' (LDS-resident fused kernel when the code qualifies, else streaming sweeps),
-        'stream', 'resident' -- both engines give identical results."""
+        """'auto' (LDS-resident fused kernel when the code qualifies, else streaming), 'stream' (HBM-streaming
+        engine; RCQ decoders run its fused one-kernel-per-iteration form), 'sweeps' (streaming, always one kernel
+        per sweep), 'resident' -- every choice gives identical results."""
         nat.check(self._lib.ldpc_decoder_set_mode(self.handle, self._MODES[mode]), "ldpc_decoder_set_mode")
-        self._ws = None
+        with self._ws_lock:
+            self._ws = {}
         return self
 
     def info(self) -> dict:
         out = np.zeros(4, dtype=np.int32)
         nat.check(self._lib.ldpc_decoder_info(self.handle, nat.ptr(out)), "ldpc_decoder_info")
-        return {"engine": {1: "stream", 2: "resident"}[int(out[0])], "codewords_per_workgroup": int(out[1]),
+        return {"engine": {1: "stream", 2: "resident", 3: "stream"}[int(out[0])],
+                "stream_form": {1: "fused-rcq-iteration", 2: None, 3: "two-sweeps"}[int(out[0])],
+                "codewords_per_workgroup": int(out[1]),
                 "threads_per_workgroup": int(out[2]), "lds_bytes": int(out[3])}
 
     # ------------------------------------------------------------------ weights
@@ -194,11 +202,17 @@ class DecodeEngine:
         return int(self._lib.ldpc_decoder_workspace_bytes(self.handle, int(batch)))
 
     def _workspace(self, batch: int) -> torch.Tensor:
+        """the current stream's scratch buffer (grown on demand, never shared between streams)"""
         need = self.workspace_bytes(batch)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        with self._ws_lock:
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                self._ws.pop(key, None)
+                ws = None
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._ws[key] = ws
+            return ws
 
     def decode(self, llr: torch.Tensor, *, early_stop: bool = True, want_bits: bool = True,
                want_posterior: bool = True, want_packed: bool = False) -> DecodeResult:
@@ -226,6 +240,15 @@ class DecodeEngine:
                                                 p(iters), p(succ), p(packed), p(ws), ws.numel(),
                                                 C.c_void_p(stream)), "ldpc_decode")
         return DecodeResult(bits, post, iters, succ.bool(), packed)
+
+    def decode_op(self, llr: torch.Tensor, *, early_stop: bool = True, want_posterior: bool = True,
+                  want_packed: bool = False) -> DecodeResult:
+        """decode() entered through the registered PyTorch operator ``torch.ops.ldpc.decode`` (torch_ops.py) --
+        the call the host decoder classes make"""
+        import torch_ops
+        bits, post, iters, succ, packed = torch.ops.ldpc.decode(llr, torch_ops.engine_handle(self), bool(early_stop),
+                                                                bool(want_posterior), bool(want_packed))
+        return DecodeResult(bits, post if want_posterior else None, iters, succ, packed if want_packed else None)
 
     # ------------------------------------------------------------------ gradients (training path)
     def _check_llr(self, llr: torch.Tensor) -> torch.Tensor:
@@ -325,8 +348,25 @@ class DecodeEngine:
                                                  C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream)),
                       "ldpc_debug_sweep")
 
+    def debug_resident_c2v(self, llr: torch.Tensor, *, early_stop: bool = True):
+        """LDS-resident engine: decode `llr` and also return every codeword's C2V messages of its last executed
+        iteration -> (c2v [B, E] dtype values in CSR edge order, posterior [B, n], iterations [B]).  Test hook
+        (include/ldpc_hip_debug.h); RCQ decoders hold reconstructed values, see `rcq_codes_from_values`."""
+        llr = self._check_llr(llr)
+        B, n = llr.shape
+        dev = self.device
+        c2v = torch.zeros((B, self.graph.E), dtype=self.dtype, device=dev)
+        post = torch.empty((B, n), dtype=self.dtype, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            p = lambda t: C.c_void_p(t.data_ptr())
+            nat.check(self._lib.ldpc_debug_resident_c2v(self.handle, p(llr), B, int(bool(early_stop)), p(post), p(iters),
+                                                        p(c2v), C.c_void_p(stream)), "ldpc_debug_resident_c2v")
+        return c2v, post, iters
+
     def debug_c2v(self, batch: int) -> torch.Tensor:
-        """C2V state left by the last decode(batch): [B, E] uint8 quantiser codes (RCQ) or
+        """Streaming engine: C2V state left by the last decode(batch): [B, E] uint8 quantiser codes (RCQ) or
         dtype values, CSR edge order.  Test hook (per-edge code parity with the reference)."""
         out8 = np.zeros(8, dtype=np.int64)
         nat.check(self._lib.ldpc_debug_workspace_layout(self.handle, int(batch), nat.ptr(out8)),

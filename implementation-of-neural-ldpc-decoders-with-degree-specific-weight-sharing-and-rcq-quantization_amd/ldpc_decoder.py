@@ -143,7 +143,7 @@ class BasicMinSumDecoder:
             dt = torch.float64 if x.dtype == torch.float64 else torch.float32
             eng = self._engine(dt, x.device if x.is_cuda else device)
             xd = x.to(device=eng.device, dtype=dt)
-        res = eng.decode(xd, early_stop=early_stop, want_posterior=False)
+        res = eng.decode_op(xd, early_stop=early_stop, want_posterior=False)     # torch.ops.ldpc.decode
         if kind == "torch" and llr.is_cuda and not single:
             return res.bits, res.success, res.iterations
         bits = res.bits.cpu().numpy().astype(np.int64)      # reference: (posterior < 0).astype(int)

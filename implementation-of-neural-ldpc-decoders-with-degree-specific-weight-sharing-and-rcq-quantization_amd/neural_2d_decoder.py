@@ -15,9 +15,11 @@ Reference behaviour mirrored (file:line in /root/reference):
   invalid sharing type -> ValueError                       neural_2d_decoder.py:81-82
 
 Extensions: ``llr`` of shape ``[B, n]`` -> ``(bits[B,n] int32, posterior[B,n] fp32,
-iterations[B] int32)``; ``early_stop=False`` keyword; inference only (the returned
-posterior carries no autograd graph -- the reference's training path does not run,
-SURVEY.md 2 #11).
+iterations[B] int32)``; ``early_stop=False`` keyword.  With autograd enabled and parameters (or the
+LLRs) requiring grad, the returned posterior carries a grad_fn back to beta / alpha (and the LLRs) exactly as
+the reference's chain of torch operations does; the derivative is computed by the HIP backward sweeps behind
+``torch.ops.ldpc.minsum_decode_train`` (torch_ops.py, autograd_bridge.py).  Under ``torch.no_grad()`` the
+decode is the plain ``torch.ops.ldpc.decode``.
 """
 
 from __future__ import annotations
@@ -108,7 +110,7 @@ class _DegreeSharedDecoder(nn.Module):
         _, x, single = _as_batch(llr, self.code.n)
         eng = self._get_engine(x.device if x.is_cuda else device)
         xd = x.detach().to(device=eng.device, dtype=torch.float32)
-        res = eng.decode(xd, early_stop=early_stop)
+        res = eng.decode_op(xd, early_stop=early_stop)            # torch.ops.ldpc.decode
         return res, single, llr.device
 
 
@@ -124,9 +126,7 @@ class _DegreeSharedDecoder(nn.Module):
             return None
         bt, at = self._sharing_layout().tables_torch(self.beta_weights, self.alpha_weights, int(self.max_iterations),
                                                      self._beta_default, self._alpha_default)
-        xd = x.detach().to(device=eng.device, dtype=torch.float32)
-        post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, xd, bool(early_stop), self._alpha_is_oms,
-                                                    x if x.requires_grad else None)
+        post, bits, iters = ab.decode_train(bt, at, eng, x, bool(early_stop), self._alpha_is_oms)
         out_dev = llr.device
         if single:
             return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())

@@ -108,12 +108,11 @@ class _EdgeWeightDecoder(nn.Module):
             where = [(t, e) for t in range(T) for e in range(g.E)]
             bt = ab.table_from_params(params, where, (max(T, 1), max(g.E, 1)), 0.0)
             at = torch.ones((max(T, 1), 1), dtype=torch.float32)
-            post, bits, iters = ab.MinSumDecodeFn.apply(bt, at, eng, x.detach().to(device=eng.device, dtype=torch.float32),
-                                                        bool(early_stop), False, x if x.requires_grad else None)
+            post, bits, iters = ab.decode_train(bt, at, eng, x, bool(early_stop), False)
             if single:
                 return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
             return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
-        res = eng.decode(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
+        res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
         if single:
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())
         return res.bits.to(out_dev), res.posterior.to(out_dev), res.iterations.to(out_dev)

@@ -158,7 +158,7 @@ class RCQMinSumDecoder:
             raise TypeError("llr must be a torch.Tensor")    # the reference needs llr.device as well
         _, x, single = _as_batch(llr, self.code.n)
         eng = self._get_engine(x.device if x.is_cuda else device)
-        res = eng.decode(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop,
+        res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop,
                          want_posterior=False)
         out_dev = llr.device
         if single:

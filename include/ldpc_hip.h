@@ -20,7 +20,10 @@
  *     work is enqueued on it, nothing synchronises, nothing allocates: the
  *     caller provides the workspace (ldpc_decoder_workspace_bytes);
  *   - handles are immutable after creation and may be shared by threads; one
- *     workspace per concurrent ldpc_decode call;
+ *     workspace per concurrent ldpc_decode call (two calls that may overlap on the
+ *     device -- different streams, different threads -- need two workspaces);
+ *   - the library reads no environment variable; measurement and test hooks live in
+ *     the separate ldpc_hip_debug.h and are never needed for decoding;
  *   - every function returns LDPC_OK (0) or a negative LDPC_ERR_*;
  *     ldpc_last_error() gives a thread-local message.
  */
@@ -102,13 +105,17 @@ typedef struct {
 int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc);
 
 /* Two engines implement the same arithmetic (bit-identical results):
- *   STREAM   : one kernel per sweep, messages in HBM ([tile][edge][W]); any code, fp32/fp64
+ *   STREAM   : messages in HBM ([tile][edge][W]); any code, fp32/fp64.  One kernel per sweep (check sweep,
+ *              variable sweep); fp32 RCQ decoders on graphs with variable degree <= 8 instead run ONE fused
+ *              kernel per iteration that recomputes the variable->check messages from the 1-byte codes and the
+ *              LLRs (no V2C array).  SWEEPS forces the two-sweep form for them too.
  *   RESIDENT : one fused kernel, messages in LDS for all T iterations; fp32 codes with
  *              dc <= 32, dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code)
- * AUTO (default) takes RESIDENT when the code qualifies. */
-enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2 };
+ * AUTO (default) takes RESIDENT when the code qualifies, else STREAM. */
+enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2, LDPC_MODE_SWEEPS = 3 };
 int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode);
-/* out4 = { engine a decode would use now (LDPC_MODE_*), codewords per workgroup, threads per
+/* out4 = { engine a decode would use now (LDPC_MODE_RESIDENT, LDPC_MODE_STREAM = streaming with the fused RCQ
+ * iteration, LDPC_MODE_SWEEPS = streaming with two sweeps per iteration), codewords per workgroup, threads per
  * workgroup, LDS bytes per workgroup } -- the last three 0 when the code does not qualify */
 int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4]);
 /* re-upload beta/alpha(/oms_alpha) tables of an existing decoder (same shapes);
@@ -133,18 +140,6 @@ size_t ldpc_decoder_workspace_bytes(const ldpc_decoder *d, int64_t batch);
 int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop,
                 int32_t *bits, void *posterior, int32_t *iterations, uint8_t *success,
                 uint8_t *packed_bits, void *workspace, size_t workspace_bytes, void *stream);
-
-/* Run ONE sweep of iteration `iter` on the state left in `workspace` by a previous
- * ldpc_decode of the same batch: which = 0 check-node (CN->VN) sweep, 1 variable-node
- * sweep.  Measurement hook for bench.py's roofline leg (HIP events around a single
- * kernel); never needed for decoding. */
-int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_t iter,
-                     void *workspace, size_t workspace_bytes, void *stream);
-
-/* Byte offsets of the state arrays inside a workspace for `batch` codewords (test and
- * measurement hook): out8 = { VEC, tiles, llrT, v2c, c2v, postT, bitsT, done }.  Messages
- * are laid out [tile][edge][W] with W = 64*VEC codewords innermost. */
-int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8]);
 
 /* ---- gradient (training) path -------------------------------------------------------------
  * Replaces torch autograd through Neural2DMinSumDecoder.forward / NeuralMinSumDecoder.forward

@@ -25,9 +25,10 @@ def inference_mode():
         yield
 
 
-@pytest.fixture(autouse=True, params=["auto", "stream"])
+@pytest.fixture(autouse=True, params=["auto", "stream", "sweeps"])
 def engine_mode(request, monkeypatch):
-    """both engines: 'auto' = LDS-resident fused kernel where the code qualifies, 'stream' = HBM sweeps"""
+    """'auto' = LDS-resident fused kernel where the code qualifies, 'stream' = HBM-streaming engine (RCQ: fused
+    one-kernel-per-iteration form), 'sweeps' = streaming with one kernel per sweep"""
     monkeypatch.setenv("LDPC_ENGINE_MODE", request.param)
     return request.param
 
@@ -171,31 +172,71 @@ def test_dvbs2_wrcq_32768_properties(gpu_device, oracle_mod):
     np.testing.assert_array_equal(res.posterior[rows].detach().cpu().numpy(), op)
 
 
-def test_bench_contract_line(gpu_device):
-    """bench.py prints ONE JSON line with the driver's keys plus the roofline and cpu_baseline objects"""
+def run_bench(extra, env_extra=None, timeout=900):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.pop("LDPC_ENGINE_MODE", None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4096",
-                          "--sweep-reps", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    for k in ("LDPC_ENGINE_MODE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("engine_mode", ["auto"], indirect=True)
+def test_bench_contract_line(gpu_device):
+    """bench.py prints ONE JSON line with the driver's keys plus the roofline and cpu_baseline objects"""
+    d = run_bench(["--steps", "2", "--warmup", "1", "--batch", "4096", "--sweep-reps", "2"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "stream_engine"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "codewords/s"
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    r = d["roofline"]                                   # dominant kernel of the step: the LDS-resident fused decode
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "hbm_formulation_equiv"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "lds" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
+    assert 0 < r["hbm"]["frac"] <= 1.0 and r["hbm"]["peak"] == 8000.0            # a real HBM rate can never exceed the peak
+    rs = d["stream_engine"]["roofline"]                 # the north_star's kernel: CN->VN sweep of the streaming engine
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rs, k
+    assert rs["bound"] == "hbm" and rs["peak"] == 8000.0 and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and d["value"] > c["value"]
+
+
+@pytest.mark.parametrize("engine_mode", ["auto"], indirect=True)
+def test_bench_default_run_carries_every_baseline_config(gpu_device):
+    """the default invocation (what the driver runs) reports configs 3, 4, 5 and the float64 Basic decoder as legs"""
+    d = run_bench(["--steps", "3", "--warmup", "1", "--leg-steps", "2", "--sweep-reps", "4", "--no-cpu-baseline"])
+    assert d["config"]["batch_per_gpu"] == 65536 and "workloads" in d
+    for w in ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64"):
+        leg = d["workloads"][w]
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and "roofline" in leg and "workload" in leg
+    assert d["workloads"]["wrcq_dvbs2"]["batch"] == 32768 and d["workloads"]["wrcq_dvbs2"]["engine"]["engine"] == "stream"
+    assert d["workloads"]["basic_f64"]["dtype"] == "f64"
+
+
+@pytest.mark.parametrize("engine_mode", ["auto"], indirect=True)
+def test_bench_bare_multi_rank_launch(gpu_device):
+    """`python bench.py --gpus N` started bare spawns its own ranks (children created before any GPU call): a 2-rank
+    gloo rehearsal on this one GPU and a 1-rank RCCL run each give exactly one JSON line with the right n_gpus"""
+    d = run_bench(["--gpus", "2", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-stream-leg"],
+                  {"LDPC_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16384 and d["scaling"] == "weak"
+    assert "all_gather" in d["config"]["collective"]
+    d = run_bench(["--gpus", "2", "--workload", "wrcq_dvbs2", "--strong", "--batch", "2048", "--steps", "1", "--warmup", "1"],
+                  {"LDPC_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 1024
+    d = run_bench(["--gpus", "1", "--force-dist", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-stream-leg",
+                   "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and "nccl" in d["config"]["collective"]

@@ -272,8 +272,9 @@ def test_zero_iterations_and_empty_batch(gpu_device):
         assert all(float(p.grad.abs().sum()) == 0.0 for p in dec3.parameters() if p.grad is not None)
 
 
-def test_second_backward_needs_recycling_off(gpu_device):
-    import autograd_bridge as ab
+def test_second_backward_follows_torch_semantics(gpu_device):
+    """the saved messages are ordinary saved tensors of the registered operator's autograd node: a second backward
+    works with retain_graph=True (gradients accumulate) and raises torch's usual error without it"""
     from ldpc_decoder import create_test_ldpc_code
     from neural_2d_decoder import Neural2DMinSumDecoder
     code = create_test_ldpc_code()
@@ -284,22 +285,62 @@ def test_second_backward_needs_recycling_off(gpu_device):
     x = torch.randn(9, code.n, device=gpu_device) + 1.0
     _, post, _ = dec(x)
     loss = codeword_loss_sum(post)
-    loss.backward(retain_graph=True)
+    loss.backward()
     g1 = param_grads(dec.beta_weights)
-    with pytest.raises(RuntimeError, match="RECYCLE_SAVED"):
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
         loss.backward()
-    ab.RECYCLE_SAVED = False
-    try:
-        dec.zero_grad()
-        _, post, _ = dec(x)
-        loss = codeword_loss_sum(post)
-        loss.backward(retain_graph=True)
-        loss.backward()                                   # accumulates: twice the gradient
-        g2 = param_grads(dec.beta_weights)
-        for k in g1:
-            assert g2[k] == pytest.approx(2 * g1[k], rel=1e-5, abs=1e-7)
-    finally:
-        ab.RECYCLE_SAVED = True
+    dec.zero_grad()
+    _, post, _ = dec(x)
+    loss = codeword_loss_sum(post)
+    loss.backward(retain_graph=True)
+    loss.backward()                                   # accumulates: twice the gradient
+    g2 = param_grads(dec.beta_weights)
+    for k in g1:
+        assert g2[k] == pytest.approx(2 * g1[k], rel=1e-5, abs=1e-7)
+
+
+def test_registered_torch_ops(gpu_device, oracle_mod):
+    """torch.ops.ldpc.* exist, pass torch.library.opcheck, and give exactly what the C-ABI path gives"""
+    import codes
+    import torch_ops
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder
+    assert hasattr(torch.ops.ldpc, "decode") and hasattr(torch.ops.ldpc, "minsum_decode_train")
+    assert hasattr(torch.ops.ldpc, "minsum_backward")
+    code = codes.load_code("small_96_48", 6)
+    dec = Neural2DMinSumDecoder(code, 2, 6)
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.fill_(0.85)
+    x = (torch.randn(37, code.n, device=gpu_device) * 1.3 + 1.5).contiguous()
+    eng = dec._get_engine(gpu_device)
+    h = torch_ops.engine_handle(eng)
+    # inference op == DecodeEngine.decode (ctypes straight into ldpc_decode)
+    direct = eng.decode(x, early_stop=True, want_packed=True)
+    bits, post, iters, succ, packed = torch.ops.ldpc.decode(x, h, True, True, True)
+    assert torch.equal(bits, direct.bits) and torch.equal(post, direct.posterior) and torch.equal(iters, direct.iterations)
+    assert torch.equal(succ, direct.success) and torch.equal(packed, direct.packed_bits)
+    torch.library.opcheck(torch.ops.ldpc.decode, (x, h, True, True, False))
+    torch.library.opcheck(torch.ops.ldpc.decode, (x, h, False, False, True))
+    rcq = RCQMinSumDecoder(code, 3, 8, [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)], max_iterations=6)
+    hr = torch_ops.engine_handle(rcq._get_engine(gpu_device))
+    torch.library.opcheck(torch.ops.ldpc.decode, (x, hr, True, False, False))
+    # training op: forward identical, gradients == the engine's own backward, opcheck incl. autograd registration
+    bt, at = dec._sharing_layout().tables_torch(dec.beta_weights, dec.alpha_weights, 6, 0.7, 1.0)
+    bt = bt.detach().clone().requires_grad_(True)
+    at = at.detach().clone().requires_grad_(True)
+    post2, bits2, iters2, saved = torch.ops.ldpc.minsum_decode_train(x, bt, at, h, True, False)
+    assert torch.equal(post2.detach(), direct.posterior) and torch.equal(bits2, direct.bits) and torch.equal(iters2, direct.iterations)
+    gp = torch.randn_like(post2)
+    post2.backward(gp)
+    res, saved_d = eng.decode_saving(x, early_stop=True)
+    gb, ga, _ = eng.backward(saved_d, x, res.iterations, gp)
+    torch.testing.assert_close(bt.grad, gb.cpu(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(at.grad, ga.cpu(), rtol=1e-5, atol=1e-6)
+    xs = x[:5].contiguous()
+    torch.library.opcheck(torch.ops.ldpc.minsum_decode_train,
+                          (xs, bt.detach().clone().requires_grad_(True), at.detach().clone().requires_grad_(True), h, True, False),
+                          test_utils=("test_schema", "test_autograd_registration", "test_faketensor"))
 
 
 @pytest.mark.parametrize("kind", ["n2d", "oms"])

@@ -233,8 +233,8 @@ def test_weight_tables_equal_oracle_flattening(name, wtype, oracle_mod):
 
 
 # ------------------------------------------------------------------ native library, no fallback
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "ldpc_hip.h")).read()
+def header_functions(header="ldpc_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ldpc_[a-z0-9_]+)\s*\(", text)))
 
@@ -245,10 +245,31 @@ def test_library_exports_every_declared_symbol():
     assert os.path.exists(lib_path), "run __graft_entry__.build() first"
     lib = ctypes.CDLL(lib_path)
     names = header_functions()
-    assert len(names) >= 11 and set(names) == set(_native.EXPORTS)
-    for name in names:
-        assert hasattr(lib, name), f"{name} declared in include/ldpc_hip.h but not exported"
+    assert len(names) >= 11 and set(names) == set(_native.PRODUCT_EXPORTS)
+    assert not any("debug" in n for n in names), "measurement/test hooks belong in ldpc_hip_debug.h"
+    dbg = header_functions("ldpc_hip_debug.h")
+    assert set(dbg) == set(_native.DEBUG_EXPORTS)
+    for name in names + dbg:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert _native.load().ldpc_abi_version() == 1
+
+
+def test_product_library_reads_no_environment():
+    """every getenv of the native sources sits inside an #ifdef LDPC_RESIDENT_PROBES block (tuning builds of tools/)"""
+    for fn in os.listdir(os.path.join(PKG, "csrc")):
+        depth = 0
+        for line in open(os.path.join(PKG, "csrc", fn)):
+            st = line.strip()
+            if st.startswith("#ifdef LDPC_RESIDENT_PROBES"):
+                depth += 1
+            elif st.startswith("#endif") and depth:
+                depth -= 1
+            elif "getenv" in line and not st.startswith("//"):
+                assert depth > 0, f"{fn}: {st}"
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(PKG, "libldpc_hip.so")],
+                          capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

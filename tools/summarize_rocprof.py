@@ -55,14 +55,32 @@ def main():
         print("wrote", out)
         tj = os.path.join(PROF, "traffic.json")
         data = json.load(open(tj)) if os.path.exists(tj) else {}
-        cn = [v for k, v in traffic.items() if k.startswith("ldpc::cn_sweep") and k.rstrip(">").endswith("false")]
-        vn = [v for k, v in traffic.items() if k.startswith("ldpc::vn_sweep") and k.rstrip(">").endswith("false")]
-        res = [v for k, v in traffic.items() if k.startswith("ldpc::resident_decode")]
-        prev = data.get(workload, {})
-        data[workload] = {"cn_sweep_bytes_per_launch": cn[0] if cn else prev.get("cn_sweep_bytes_per_launch"),
-                          "vn_sweep_bytes_per_launch": vn[0] if vn else prev.get("vn_sweep_bytes_per_launch"),
-                          "resident_decode_bytes_per_launch": res[0] if res else prev.get("resident_decode_bytes_per_launch"),
-                          "source": f"{tag}_{workload}_pmc.csv", "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+        # Every number records the file it came from; a kernel that this pass did not measure is DROPPED from the
+        # workload's entry (bench.py then reports traffic null) instead of inheriting an older build's figure.
+        entry = {"correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+        src = f"{tag}_{workload}_pmc.csv"
+
+        def pick(prefix, steady=True):
+            # the steady-state instantiation: FIRST = false sweeps (template argument list ends in "false" for vn LAST=false;
+            # cn_sweep<T, VEC, FORM, FIRST, ...> has FIRST as its 4th argument)
+            best = None
+            for k, v in traffic.items():
+                if not k.startswith("ldpc::" + prefix):
+                    continue
+                args = k[k.index("<") + 1:k.rindex(">")].split(", ") if "<" in k else []
+                if prefix == "cn_sweep" and len(args) >= 4 and args[3] != "false":
+                    continue
+                if prefix == "vn_sweep" and len(args) >= 4 and args[3] != "false":
+                    continue
+                if best is None or v > best:
+                    best = v
+            return best
+
+        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather"):
+            v = pick(key)
+            if v is not None:
+                entry[key] = {"bytes_per_launch": v, "source": src}
+        data[workload] = entry
         json.dump(data, open(tj, "w"), indent=1)
         print("wrote", tj)
 

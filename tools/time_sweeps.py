@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--packed", action="store_true", help="also ask for the bit-packed hard decisions (multi-GPU wire format)")
     ap.add_argument("--tag", default=os.environ.get("LDPC_HIP_LIB", "default"))
+    ap.add_argument("--mode", default="", help="engine mode: auto | stream | sweeps | resident")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -27,9 +28,11 @@ def main():
         eng = dec._engine(torch.float32, dev)
         T, B = 10, a.batch or 65536
     else:
-        gname, T, B0, _ = bench.WORKLOADS[a.workload]
+        gname, T, B0 = bench.WORKLOADS[a.workload][:3]
         B = a.batch or B0
         eng, dec, code = bench.build_decoder(a.workload, dev)
+    if a.mode:
+        eng.set_mode(a.mode)
     llr = bench.make_llr(B, code.n, 2.0, 1234, dev)
     for _ in range(2):
         eng.decode(llr, early_stop=False, want_posterior=False, want_packed=a.packed)
@@ -40,7 +43,7 @@ def main():
     for _ in range(5):
         eng.decode(llr, early_stop=False, want_posterior=False, want_packed=a.packed)
     e1.record(); e1.synchronize()
-    out = {"tag": os.path.basename(a.tag), "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5,
+    out = {"tag": os.path.basename(a.tag), "mode": a.mode, "workload": a.workload, "B": B, "decode_ms": e0.elapsed_time(e1) / 5,
            "engine": eng.info()}
     out["Mcw_s"] = B / out["decode_ms"] / 1e3
     out["ns_per_edge_iter"] = out["decode_ms"] * 1e6 / (B * T * code.tanner_graph().E)
