@@ -100,6 +100,10 @@ struct ldpc_decoder {
     size_t res_lds = 0;
     ResidentPlan res{};
     std::vector<void *> res_bufs;  // device allocations owned by the plan
+    // inverse slot maps of the gradient path (reduce_table_grads): items of slot s = inv_items[inv_ptr[s] .. inv_ptr[s+1])
+    int *beta_inv_ptr = nullptr, *beta_inv_items = nullptr;
+    int *alpha_inv_ptr = nullptr, *alpha_inv_items = nullptr;
+    int *oms_inv_ptr = nullptr, *oms_inv_items = nullptr;
     // fused RCQ iteration of the streaming engine (cn_gather): per-edge gather metadata, built at creation for fp32
     // flooding RCQ decoders on graphs with variable degree <= 8
     bool gat_ok = false;
@@ -264,15 +268,15 @@ int launch_gather(const ldpc_decoder *d, const Workspace &w, int it, bool use_do
     const float *beta_row = (const float *)d->beta + (size_t)it * d->n_beta;
     const float *alpha_prev = (const float *)d->alpha + (size_t)(it - 1) * d->n_alpha;
     const float *thr = d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels;
-    const int lut_stride = 2 * d->n_levels, lut_total = d->n_quant * lut_stride;
-    const int lut_prev = d->q_of_iter[it - 1] * lut_stride;
-    const size_t shmem = (size_t)lut_total * sizeof(float);
+    const int lut_entries = 2 * d->n_levels;
+    const float *lut_prev = d->lut + (size_t)d->q_of_iter[it - 1] * lut_entries;     // the quantiser that produced `cin`
+    const size_t shmem = (size_t)lut_entries * sizeof(float);
     const uint64_t *done = use_done ? w.done : nullptr;
 #define LDPC_GA(NL_, BPC_, CPW_)                                                                                     \
-    hipLaunchKernelGGL((cn_gather<VEC, NL_, BPC_, CPW_>), grid, block, shmem, s, g, (const int4 *)d->gat_meta,        \
-                       (const int *)d->gat_nbr, (const float *)w.llrT, (const uint8_t *)cin, (uint8_t *)cout, beta_row, \
-                       (const int *)d->beta_slot, alpha_prev, thr, d->n_levels, (const float *)d->lut, lut_total,      \
-                       lut_prev, done, cb)
+    hipLaunchKernelGGL((cn_gather<VEC, NL_, BPC_, CPW_, LDPC_GATHER_GRP>), grid, block, shmem, s, g,                  \
+                       (const int4 *)d->gat_meta, (const int *)d->gat_nbr, (const float *)w.llrT, (const uint8_t *)cin, \
+                       (uint8_t *)cout, beta_row, (const int *)d->beta_slot, alpha_prev, thr, d->n_levels, lut_prev,   \
+                       lut_entries, done, cb)
     const int variant = (d->n_levels == 4 ? 4 : 0) + (d->beta_per_check ? 2 : 0) + (cpw == 2 ? 1 : 0);
     switch (variant) {
     case 0: LDPC_GA(0, false, 1); break;
@@ -957,8 +961,23 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
         rc = up_bytes(&d->oms_alpha, desc->oms_alpha, rows * d->n_oms_alpha * es);
         if (!rc) rc = upload(&d->oms_alpha_slot, desc->oms_alpha_slot, (size_t)g->E);
     }
+    if (!rc && d->dtype == LDPC_F32 && d->form != LDPC_C2V_RCQ && d->schedule == LDPC_SCHED_FLOODING) {
+        auto invert = [&](const int32_t *slot, int count, int n_slots, int **ptr_dev, int **items_dev) {
+            std::vector<int> ptr((size_t)n_slots + 1, 0), items((size_t)std::max(count, 1), 0);
+            for (int x = 0; x < count; ++x) ptr[slot[x] + 1]++;
+            for (int k = 0; k < n_slots; ++k) ptr[k + 1] += ptr[k];
+            std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+            for (int x = 0; x < count; ++x) items[fill[slot[x]]++] = x;         // ascending x inside a slot
+            int r = upload(ptr_dev, ptr.data(), ptr.size());
+            if (!r) r = upload(items_dev, items.data(), items.size());
+            return r;
+        };
+        rc = invert(desc->beta_slot, g->E, d->n_beta, &d->beta_inv_ptr, &d->beta_inv_items);
+        if (!rc) rc = invert(desc->alpha_slot, g->n, d->n_alpha, &d->alpha_inv_ptr, &d->alpha_inv_items);
+        if (!rc && d->oms_alpha) rc = invert(desc->oms_alpha_slot, g->E, d->n_oms_alpha, &d->oms_inv_ptr, &d->oms_inv_items);
+    }
     if (!rc && d->form == LDPC_C2V_RCQ && d->dtype == LDPC_F32 && d->schedule == LDPC_SCHED_FLOODING &&
-        g->E > 0 && g->max_dv <= 8) {
+        g->E > 0 && g->max_dv <= 8 && (long long)g->E * 256 < (1ll << 31) && (long long)g->n * 1024 < (1ll << 31)) {
         // gather metadata of the fused RCQ iteration (cn_gather): per CSR edge its variable, where the list of
         // the variable's OTHER edges starts (ascending check order = CSC order), how many there are, alpha column
         std::vector<int4> meta((size_t)g->E + 1);
@@ -1041,6 +1060,8 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipFree(d->thresholds); (void)hipFree(d->lut); (void)hipFree(d->q_of_iter_dev);
     for (void *p : d->res_bufs) (void)hipFree(p);
     (void)hipFree(d->gat_meta); (void)hipFree(d->gat_nbr);
+    (void)hipFree(d->beta_inv_ptr); (void)hipFree(d->beta_inv_items); (void)hipFree(d->alpha_inv_ptr);
+    (void)hipFree(d->alpha_inv_items); (void)hipFree(d->oms_inv_ptr); (void)hipFree(d->oms_inv_items);
     delete d;
 }
 
@@ -1165,21 +1186,19 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     HIP_TRY(hipGetLastError());
     if (grad_llr)
         hipLaunchKernelGGL((untranspose_rows<VEC>), tgrid, blk, 0, s, (const float *)w.gllrT, grad_llr, (long long)batch, g.n, vc);
-    if (grad_beta) {
-        HIP_TRY(hipMemsetAsync(grad_beta, 0, (size_t)T * d->n_beta * 4, s));
-        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                           (const float *)w.gbeta, w.tiles, g.E, (const int *)d->beta_slot, d->n_beta, grad_beta);
-    }
-    if (grad_oms_alpha && d->form == LDPC_C2V_OMS && d->oms_alpha) {
-        HIP_TRY(hipMemsetAsync(grad_oms_alpha, 0, (size_t)T * d->n_oms_alpha * 4, s));
-        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.E + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                           (const float *)w.goa, w.tiles, g.E, (const int *)d->oms_alpha_slot, d->n_oms_alpha, grad_oms_alpha);
-    }
-    if (grad_alpha) {
-        HIP_TRY(hipMemsetAsync(grad_alpha, 0, (size_t)T * d->n_alpha * 4, s));
-        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)((g.n + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                           (const float *)w.galpha, w.tiles, g.n, (const int *)d->alpha_slot, d->n_alpha, grad_alpha);
-    }
+    // fixed-order reductions (one wave per slot and iteration): every table entry is written, no memset, no atomics
+    if (grad_beta)
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)d->n_beta, (unsigned)T), dim3(kWave), 0, s,
+                           (const float *)w.gbeta, w.tiles, g.E, (const int *)d->beta_inv_ptr,
+                           (const int *)d->beta_inv_items, d->n_beta, grad_beta);
+    if (grad_oms_alpha && d->form == LDPC_C2V_OMS && d->oms_alpha)
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)d->n_oms_alpha, (unsigned)T), dim3(kWave), 0, s,
+                           (const float *)w.goa, w.tiles, g.E, (const int *)d->oms_inv_ptr,
+                           (const int *)d->oms_inv_items, d->n_oms_alpha, grad_oms_alpha);
+    if (grad_alpha)
+        hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)d->n_alpha, (unsigned)T), dim3(kWave), 0, s,
+                           (const float *)w.galpha, w.tiles, g.n, (const int *)d->alpha_inv_ptr,
+                           (const int *)d->alpha_inv_items, d->n_alpha, grad_alpha);
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }

@@ -51,6 +51,14 @@ struct alignas(sizeof(T) * V) Pack {
 #ifndef LDPC_CN_UNROLL
 #define LDPC_CN_UNROLL 4
 #endif
+#ifndef LDPC_GATHER_GRP
+#define LDPC_GATHER_GRP 2      // edges per load group of the fused RCQ iteration kernel (cn_gather); measured on the
+                               // (16200,7200) code: 2 edges / 5 waves 2.22 ms per launch, 3/4: 2.40, 4/4: 2.43, 4/3: 2.87,
+                               // 6/2: 3.85, 8/2: 3.94 (occupancy beats deeper groups: the kernel is issue- and latency-bound)
+#endif
+#ifndef LDPC_GATHER_WAVES
+#define LDPC_GATHER_WAVES 5    // waves per SIMD the register allocation of cn_gather must leave room for
+#endif
 
 template <typename T, int V>
 __device__ __forceinline__ Pack<T, V> ld(const T *p)
@@ -655,32 +663,46 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
 // Same wave mapping as cn_sweep (wave = one check x W codewords, every index wave-uniform); per-edge gather
 // metadata is precomputed by the host: meta[e] = {variable, offset into nbr, dv-1, alpha column}, nbr[] = CSR
 // edge ids of the variable's other edges in ascending check order (the reference's summation order).
-// The next edge's metadata, neighbour ids and LLR row are fetched while the current edge is processed.
 // ------------------------------------------------------------------------------------------
 //   gat_meta [E + 1]              (one padding entry: the prefetch of "the edge after the last" stays in bounds)
 //   gat_nbr  [sum_j dv(dv-1) + 8] (padded: eight ids are always fetched)
 
-template <int VEC, int CNT>
-__device__ __forceinline__ Pack<float, VEC> gather_v2c(const uint8_t *__restrict__ codes, const int (&nb)[8],
-                                                       const Pack<float, VEC> &l, float a, const Lut<VEC> &lut)
+// Row loads of the gather kernel: buffer_load with the tile's base in a wave-uniform 128-bit descriptor, the row's byte
+// offset in an SGPR (soffset) and the lane's offset inside the row in one VGPR (voffset) -- no VALU address arithmetic
+// and no 64-bit VGPR address pairs.  aux = 2: non-temporal, as the other message streams.
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> buf_ld(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_byte, unsigned row_byte)
 {
-    constexpr int W = kWave * VEC;
-    Pack<uint8_t, VEC> q[CNT > 0 ? CNT : 1];
-#pragma unroll
-    for (int k = 0; k < CNT; ++k) q[k] = ld<uint8_t, VEC>(codes + (size_t)nb[k] * W);
+    constexpr int kBytes = (int)sizeof(T) * V;
+    static_assert(kBytes == 1 || kBytes == 4 || kBytes == 16, "row element of 1, 4 or 16 bytes per lane");
+    union { Pack<T, V> k; unsigned char b; unsigned w; unsigned q __attribute__((ext_vector_type(4))); } u;
+    if constexpr (kBytes == 1) u.b = __builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)lane_byte, (int)row_byte, 2);
+    else if constexpr (kBytes == 4) u.w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_byte, (int)row_byte, 2);
+    else u.q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_byte, (int)row_byte, 2);
+    return u.k;
+}
+
+// v2c = llr + alpha * sum(reconstructed codes) for CNT other edges whose code rows are already in registers
+template <int VEC, int CNT>
+__device__ __forceinline__ Pack<float, VEC> gather_v2c(const Pack<uint8_t, VEC> (&q)[7], const Pack<float, VEC> &l, float a,
+                                                       const float *__restrict__ lut)
+{
     Pack<float, VEC> out;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
         float xs[CNT > 0 ? CNT : 1];
 #pragma unroll
-        for (int k = 0; k < CNT; ++k) xs[k] = lut.base[lut.off[c] + q[k].x[c]];
+        for (int k = 0; k < CNT; ++k) xs[k] = lut[q[k].x[c]];
         out.x[c] = l.x[c] + a * sum_ct<CNT, -1, 0, float>(xs);      // same expression as vn_body (alpha * 0 for dv = 1)
     }
     return out;
 }
 
-template <int VEC, int NL, bool BPC, int CPW>
-__global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__restrict__ gat_meta,
+// GRP: edges whose rows (LLR + code rows of the other edges) are requested together before any of them is
+// consumed.  The kernel is bound by memory latency, not bandwidth (its reads are L2/MALL hits of 256 B - 1 KiB rows):
+// one exposed round trip per GRP edges instead of one per edge.
+template <int VEC, int NL, bool BPC, int CPW, int GRP>
+__global__ __launch_bounds__(kBlock, LDPC_GATHER_WAVES) void cn_gather(GraphDev g, const int4 *__restrict__ gat_meta,
                                                     const int *__restrict__ gat_nbr, const float *__restrict__ llrT,
                                                     const uint8_t *__restrict__ codes_in,
                                                     uint8_t *__restrict__ codes_out,
@@ -688,13 +710,15 @@ __global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__re
                                                     const int *__restrict__ beta_slot,
                                                     const float *__restrict__ alpha_prev_row,
                                                     const float *__restrict__ thr, int n_levels,
-                                                    const float *__restrict__ lut_global, int lut_total,
-                                                    int lut_prev_off, const uint64_t *__restrict__ done,
-                                                    int check_blocks)
+                                                    const float *__restrict__ lut_prev, int lut_entries,
+                                                    const uint64_t *__restrict__ done, int check_blocks)
 {
     constexpr int W = kWave * VEC;
+    // reconstruction values of the PREVIOUS iteration's quantiser (the one that produced codes_in), at LDS offset 0.
+    // Codewords the early-stop latch froze earlier would need their own quantiser's table -- but their outputs are
+    // never stored (store_latched keeps their old codes), so any table will do for them.
     extern __shared__ float gather_lut_s[];
-    for (int k = threadIdx.x; k < lut_total; k += kBlock) gather_lut_s[k] = lut_global[k];
+    for (int k = threadIdx.x; k < lut_entries; k += kBlock) gather_lut_s[k] = lut_prev[k];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
     const int tile = uni(blockIdx.x / check_blocks);
@@ -706,16 +730,15 @@ __global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__re
     float th[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
-    Lut<VEC> lut;
-    lut.base = gather_lut_s;
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) lut.off[c] = lut_prev_off;       // frozen codewords: their stores are masked anyway
-    const size_t lane_off = (size_t)lane * VEC;
-    const float *llr_tile = llrT + (size_t)tile * g.n * W + lane_off;
-    const uint8_t *cin_tile = codes_in + (size_t)tile * g.E * W + lane_off;
-    uint8_t *cout_tile = codes_out + (size_t)tile * g.E * W + lane_off;
+    const unsigned lane_f = (unsigned)lane * VEC * (unsigned)sizeof(float);     // byte offset inside an LLR row
+    const unsigned lane_b = (unsigned)lane * VEC;                               // byte offset inside a code row
+    const uint8_t *cin_tile = codes_in + (size_t)tile * g.E * W;
+    uint8_t *cout_tile = codes_out + (size_t)tile * g.E * W;
+    // descriptors of this tile's LLR rows and code rows (the host admits only graphs whose tile fits 31 bits of bytes)
+    const __amdgpu_buffer_rsrc_t llr_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(llrT + (size_t)tile * g.n * W), 0, g.n * W * (int)sizeof(float), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(cin_tile), 0, g.E * W, 0x00020000);
 
-#pragma unroll
     for (int cc_ = 0; cc_ < CPW; ++cc_) {
     const int i = ibase + cc_;
     if (i >= g.m) break;
@@ -724,33 +747,54 @@ __global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__re
     if (dc == 0) continue;
     if (all_frozen) {                              // the codes are double-buffered: carry the tile's latched rows over
         for (int t = 0; t < dc; ++t)
-            st<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W, ld<uint8_t, VEC>(cin_tile + (size_t)(e0 + t) * W));
+            st<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W + lane_b, ld<uint8_t, VEC>(cin_tile + (size_t)(e0 + t) * W + lane_b));
         continue;
     }
 
-    // one edge's variable->check message, recomputed from the previous iteration's codes
-    struct Edge { int4 md; int nb[8]; Pack<float, VEC> l; };
-    auto fetch = [&](int e, Edge &x) {
-        x.md = gat_meta[e];
-        const int *np = gat_nbr + x.md.y;
+    // variable->check messages of the edges t0 .. t0+GRP-1 of this check, recomputed from the previous codes
+    auto group = [&](int t0, auto &&consume) {
+        int4 md[GRP];
+        int nb[GRP][8];
+        Pack<float, VEC> l[GRP];
+        Pack<uint8_t, VEC> q[GRP][7];
+        // scalar phase: the group's metadata, then its neighbour lists (eight ids each, the lists are padded), each
+        // batch issued back to back -- two scalar round trips per group
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x.nb[k] = np[k];               // padded lists: reading 8 is always in bounds
-        x.l = ld<float, VEC>(llr_tile + (size_t)x.md.x * W);
-    };
-    auto value = [&](const Edge &x) -> Pack<float, VEC> {
-        const float a = alpha_prev_row[uni(x.md.w)];
-        int nb[8];
+        for (int u = 0; u < GRP; ++u) md[u] = gat_meta[min(e0 + t0 + u, g.E)];          // entry E is padding (no other edges)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nb[k] = uni(x.nb[k]);
-        switch (uni(x.md.z)) {
-        case 0: return gather_v2c<VEC, 0>(cin_tile, nb, x.l, a, lut);
-        case 1: return gather_v2c<VEC, 1>(cin_tile, nb, x.l, a, lut);
-        case 2: return gather_v2c<VEC, 2>(cin_tile, nb, x.l, a, lut);
-        case 3: return gather_v2c<VEC, 3>(cin_tile, nb, x.l, a, lut);
-        case 4: return gather_v2c<VEC, 4>(cin_tile, nb, x.l, a, lut);
-        case 5: return gather_v2c<VEC, 5>(cin_tile, nb, x.l, a, lut);
-        case 6: return gather_v2c<VEC, 6>(cin_tile, nb, x.l, a, lut);
-        default: return gather_v2c<VEC, 7>(cin_tile, nb, x.l, a, lut);    // host admits dv <= 8 to this kernel
+        for (int u = 0; u < GRP; ++u) {
+            const int *np = gat_nbr + md[u].y;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nb[u][k] = np[k];
+        }
+        // vector phase: every row of the group requested before the first is consumed
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            if (t0 + u < dc) {
+                l[u] = buf_ld<float, VEC>(llr_rs, lane_f, (unsigned)md[u].x * (unsigned)(W * sizeof(float)));
+                const int cnt = md[u].z;
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    if (k < cnt) q[u][k] = buf_ld<uint8_t, VEC>(cin_rs, lane_b, (unsigned)nb[u][k] * (unsigned)W);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            if (t0 + u < dc) {
+                const float a = alpha_prev_row[md[u].w];
+                Pack<float, VEC> v;
+                switch (md[u].z) {
+                case 0: v = gather_v2c<VEC, 0>(q[u], l[u], a, gather_lut_s); break;
+                case 1: v = gather_v2c<VEC, 1>(q[u], l[u], a, gather_lut_s); break;
+                case 2: v = gather_v2c<VEC, 2>(q[u], l[u], a, gather_lut_s); break;
+                case 3: v = gather_v2c<VEC, 3>(q[u], l[u], a, gather_lut_s); break;
+                case 4: v = gather_v2c<VEC, 4>(q[u], l[u], a, gather_lut_s); break;
+                case 5: v = gather_v2c<VEC, 5>(q[u], l[u], a, gather_lut_s); break;
+                case 6: v = gather_v2c<VEC, 6>(q[u], l[u], a, gather_lut_s); break;
+                default: v = gather_v2c<VEC, 7>(q[u], l[u], a, gather_lut_s); break;   // host admits dv <= 8 here
+                }
+                consume(u, v);
+            }
         }
     };
 
@@ -761,21 +805,19 @@ __global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__re
 #pragma unroll
     for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); idx[c] = 0; sm[c] = 0; par[c] = 0; }
 
-    Edge cur, nxt;
-    fetch(e0, cur);
-    for (int t = 0; t < dc; ++t) {
-        fetch(e0 + t + 1, nxt);                    // in flight across this edge's gather (meta is padded by one entry)
-        const Pack<float, VEC> v = value(cur);
+    for (int t0 = 0; t0 < dc; t0 += GRP) {
+        group(t0, [&](int u, const Pack<float, VEC> &v) {
+            const int t = t0 + u;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            const float a = __builtin_fabsf(v.x[c]);
-            const unsigned sb = signbit_of<float>(v.x[c]);
-            par[c] ^= sb;
-            sm[c] |= sb << (t & 31);
-            if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; idx[c] = t; }
-            else if (a < m2[c]) { m2[c] = a; }
-        }
-        cur = nxt;
+            for (int c = 0; c < VEC; ++c) {
+                const float a = __builtin_fabsf(v.x[c]);
+                const unsigned sb = signbit_of<float>(v.x[c]);
+                par[c] ^= sb;
+                sm[c] |= sb << (t & 31);
+                if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; idx[c] = t; }
+                else if (a < m2[c]) { m2[c] = a; }
+            }
+        });
     }
     if (dc == 1) {
 #pragma unroll
@@ -810,32 +852,32 @@ __global__ __launch_bounds__(kBlock) void cn_gather(GraphDev g, const int4 *__re
             cc2[c] = (l2 + (s2 ? z2 : 0u)) | ((l2 + (s2 ? 0u : z2)) << 8);
         }
     }
-    if (wide) fetch(e0, cur);
-    for (int t = 0; t < dc; ++t) {
-        Pack<float, VEC> re;
-        if (wide) {
-            fetch(e0 + t + 1, nxt);
-            re = value(cur);
-            cur = nxt;
-        }
-        Pack<uint8_t, VEC> o;
-        float b = 0.0f;
-        if constexpr (!BPC) b = beta_row[beta_slot[e0 + t]];
+    for (int t0 = 0; t0 < dc; t0 += GRP) {
+        Pack<float, VEC> re[GRP];
+        if (wide) group(t0, [&](int u, const Pack<float, VEC> &v) { re[u] = v; });
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            const unsigned own = wide ? signbit_of<float>(re.x[c]) : ((sm[c] >> (t & 31)) & 1u);
-            const unsigned neg = par[c] ^ own;
-            if constexpr (BPC) {
-                const unsigned cc = (t == idx[c]) ? cc2[c] : cc1[c];
-                o.x[c] = (uint8_t)((cc >> (neg * 8u)) & 0xffu);
-            } else {
-                const float raw = (t == idx[c]) ? m2[c] : m1[c];
-                const float w = flip_sign<float>(b * raw, neg);
-                const int lvl = level(__builtin_fabsf(w));
-                o.x[c] = (uint8_t)(((w < 0.0f) ? n_levels : 0) + lvl);                    // rcq_decoder.py:88-89
+        for (int u = 0; u < GRP; ++u) {
+            const int t = t0 + u;
+            if (t >= dc) break;
+            Pack<uint8_t, VEC> o;
+            float b = 0.0f;
+            if constexpr (!BPC) b = beta_row[beta_slot[e0 + t]];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const unsigned own = wide ? signbit_of<float>(re[u].x[c]) : ((sm[c] >> (t & 31)) & 1u);
+                const unsigned neg = par[c] ^ own;
+                if constexpr (BPC) {
+                    const unsigned cc = (t == idx[c]) ? cc2[c] : cc1[c];
+                    o.x[c] = (uint8_t)((cc >> (neg * 8u)) & 0xffu);
+                } else {
+                    const float raw = (t == idx[c]) ? m2[c] : m1[c];
+                    const float w = flip_sign<float>(b * raw, neg);
+                    const int lvl = level(__builtin_fabsf(w));
+                    o.x[c] = (uint8_t)(((w < 0.0f) ? n_levels : 0) + lvl);                    // rcq_decoder.py:88-89
+                }
             }
+            store_latched<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W + lane_b, done ? cin_tile + (size_t)(e0 + t) * W + lane_b : nullptr, o, fz);
         }
-        store_latched<uint8_t, VEC>(cout_tile + (size_t)(e0 + t) * W, done ? cin_tile + (size_t)(e0 + t) * W : nullptr, o, fz);
     }
     }   // checks of this wave
 }

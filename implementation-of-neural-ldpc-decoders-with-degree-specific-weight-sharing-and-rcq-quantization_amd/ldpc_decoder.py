@@ -8,6 +8,9 @@ Reference behaviour mirrored (file:line in /root/reference):
   LDPCCode dataclass, rate, degree dicts                ldpc_decoder.py:26-54
   BasicMinSumDecoder(code, factor=0.7).decode(llr)      ldpc_decoder.py:56-153
       -> (np.ndarray[n] int64, bool, int); T = code.max_iterations
+  NeuralMinSumDecoder(code, max_iterations=50)          ldpc_decoder.py:155-272
+      the edge-weight decoder this module ALSO defines in the reference (weights randn*0.1, no +0.7);
+      resolved lazily from neural_minsum_decoder.py (which imports this module)
   create_test_ldpc_code(): 4x7 H, max_iterations=10     ldpc_decoder.py:274-284
   simulate_awgn_channel(codeword, snr_db)               ldpc_decoder.py:286-302
 
@@ -178,3 +181,12 @@ def simulate_awgn_channel(codeword: np.ndarray, snr_db: float) -> np.ndarray:
     noise = np.random.normal(0, np.sqrt(noise_power), len(bpsk_symbols))
     received = bpsk_symbols + noise
     return 2 * received / noise_power
+
+
+def __getattr__(name):
+    # `from ldpc_decoder import NeuralMinSumDecoder` (the reference defines one here too, :155); lazy because
+    # neural_minsum_decoder imports LDPCCode from this module
+    if name == "NeuralMinSumDecoder":
+        from neural_minsum_decoder import LdpcDecoderNeuralMinSumDecoder
+        return LdpcDecoderNeuralMinSumDecoder
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

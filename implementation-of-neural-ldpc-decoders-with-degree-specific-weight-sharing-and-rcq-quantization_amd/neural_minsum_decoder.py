@@ -131,6 +131,21 @@ class NeuralMinSumDecoder(_EdgeWeightDecoder):
         logger.info(f"Total edges: {num_edges}, Parameters per iteration: {num_edges}")
 
 
+class LdpcDecoderNeuralMinSumDecoder(_EdgeWeightDecoder):
+    """The SECOND NeuralMinSumDecoder the reference ships, inside ldpc_decoder.py (:155-272): the same per-edge
+    normalised min-sum forward, but weights initialised ``randn*0.1`` WITHOUT the +0.7 and an (empty)
+    ``alpha_weights`` ParameterDict.  Exported as ``ldpc_decoder.NeuralMinSumDecoder``."""
+
+    def __init__(self, code: LDPCCode, max_iterations: int = 50):
+        super().__init__()
+        self._init_edges(code, max_iterations, offset=0.0)
+        self.alpha_weights = nn.ParameterDict()
+        logger.info(f"Initialized Neural MinSum decoder with {len(self.beta_weights)} parameters")
+
+
+LdpcDecoderNeuralMinSumDecoder.__name__ = LdpcDecoderNeuralMinSumDecoder.__qualname__ = "NeuralMinSumDecoder"
+
+
 class NeuralOffsetMinSumDecoder(_EdgeWeightDecoder):
     """Neural Offset MinSum (N-OMS) decoder with edge-specific offsets"""
 

@@ -207,3 +207,30 @@ class GradientExplosionAnalyzer:
         _plot_series([("hist", results["gradient_magnitudes"], "Gradient Magnitude Distribution", "Gradient Magnitude", "Frequency"),
                       ("scatter", (results["iteration_counts"], results["gradient_magnitudes"]),
                        "Gradient Magnitude vs Iterations", "Iterations", "Gradient Magnitude")], (12, 5), save_path)
+
+
+def create_dvbs2_code(reference_dense: bool = False) -> LDPCCode:
+    """Create a DVBS-2 LDPC code for testing -- the (16200, 7200) code the reference's callers ask for
+    (training_framework.py:379-400; examples.py:360, simulation_framework.py:428), ``max_iterations=50``.
+
+    Deviation, stated: the reference fills a dense 9000 x 16200 matrix with ``np.random.randint(0, 2)`` (check
+    degree ~8100, variable degree ~4500, 73 M edges) -- not an LDPC matrix, and its own per-edge Python loops
+    cannot decode one vector of it in practical time.  By default this returns the committed DVB-S2-LIKE sparse
+    code of the same dimensions (``codes.load_code("dvbs2_like_16200_7200")``: IRA staircase, E = 48599, the node
+    degree profile of the paper's Table II), which every decoder of this package runs.
+    ``reference_dense=True`` reproduces the reference's matrix bit for bit (same global-RNG draws, ~1.2 GB while it
+    is being drawn); its degrees lie beyond the summation orders the engine restates, so decoding it raises
+    NotImplementedError."""
+    n, k = 16200, 7200
+    if not reference_dense:
+        import codes
+        return codes.load_code("dvbs2_like_16200_7200", max_iterations=50)
+    np.random.seed(42)
+    H = np.random.randint(0, 2, (n - k, n))
+    for i in range(n - k):
+        if np.sum(H[i, :]) == 0:
+            H[i, np.random.randint(0, n)] = 1
+    for j in range(n):
+        if np.sum(H[:, j]) == 0:
+            H[np.random.randint(0, n - k), j] = 1
+    return LDPCCode(n=n, k=k, H=H, max_iterations=50)

@@ -165,11 +165,39 @@ def test_basic_fp32_vs_oracle_and_fp64_reference(gpu_device, oracle_mod):
     np.testing.assert_array_equal(bits, ob)
     np.testing.assert_array_equal(iters, oi)
     np.testing.assert_array_equal(succ, os_)
-    # fp32 engine vs fp64 reference: same decisions wherever the fp64 posterior is not tiny
-    safe = np.abs(g["oracle_posterior"]) > 1e-3
-    same_iters = iters == g["iters"]
-    assert same_iters.mean() >= 0.9
-    assert np.all((bits == g["bits"])[same_iters][safe[same_iters]])
+    # fp32 engine vs the float64 REFERENCE outputs on the reference's own inputs: measured identical (BASELINE.md 6,
+    # tools/f32_vs_f64.py) -- every iteration count, success flag and bit of the 16 golden codewords
+    np.testing.assert_array_equal(iters, g["iters"])
+    np.testing.assert_array_equal(succ, g["success"])
+    np.testing.assert_array_equal(bits, g["bits"])
+
+
+@pytest.mark.parametrize("snr_db,max_cw_frac", [(2.0, 5e-4), (5.0, 1e-4)])
+def test_basic_fp32_vs_fp64_mismatch_rate_is_bounded(snr_db, max_cw_frac, gpu_device, engine_mode):
+    """The benchmark computes BasicMinSumDecoder in fp32 (BASELINE.json north_star) where the reference computes in
+    float64 (ldpc_decoder.py:80-81, 116-120).  Quantified on a fresh 65536-codeword batch with the float64 kernels
+    (bit-exact against the reference goldens) as the yardstick -- measured on MI355X: at 2 dB 3 of
+    65536 codewords differ in any bit (4.6e-5; 2.3e-8 of the bits) and no iteration count differs; at 5 dB nothing
+    differs.  The bounds asserted here are 10x the measurement."""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    if engine_mode != "auto":
+        pytest.skip("one engine suffices: the engines give identical results (every other test checks that)")
+    code = codes.load_code("ira_1998_1512", 10)
+    dec = BasicMinSumDecoder(code, 0.7)
+    s2 = 10.0 ** (-snr_db / 10.0)
+    gen = torch.Generator(device=gpu_device)
+    gen.manual_seed(1234)
+    z = torch.randn((65536, code.n), generator=gen, device=gpu_device, dtype=torch.float32)
+    x64 = (2.0 * (1.0 + (s2 ** 0.5) * z) / s2).double()
+    for early in (True, False):
+        b64, s64, i64 = dec.decode(x64, early_stop=early)
+        b32, s32, i32 = dec.decode(x64.float(), early_stop=early)
+        cw_differs = (b64 != b32).any(dim=1).float().mean().item()
+        assert cw_differs <= max_cw_frac, f"{cw_differs} of the codewords differ in a bit"
+        assert (i64 != i32).float().mean().item() <= max_cw_frac
+        assert (s64 != s32).float().mean().item() <= max_cw_frac
+        assert (b64 != b32).float().mean().item() <= 1e-6
 
 
 # --------------------------------------------------------------------------------- Neural 2D

@@ -310,3 +310,31 @@ def test_decoder_objects_pickle_without_native_handles():
     dec = Neural2DMinSumDecoder(codes.load_code("small_96_48", 10), 2, 4)
     dec2 = copy.deepcopy(dec)
     assert dec2._engine is None and list(dec2.state_dict()) == list(dec.state_dict())
+
+
+def test_reference_import_lines_work_verbatim():
+    """the import statements of the reference's own callers (examples.py:17-22, comprehensive_test.py:15-20,
+    simulation_framework.py:19-23, training_framework.py:14-16) resolve against this package unchanged"""
+    ns = {}
+    exec("from ldpc_decoder import LDPCCode, BasicMinSumDecoder, create_test_ldpc_code, simulate_awgn_channel\n"
+         "from neural_minsum_decoder import NeuralMinSumDecoder, NeuralOffsetMinSumDecoder, analyze_weight_patterns\n"
+         "from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder\n"
+         "from rcq_decoder import RCQMinSumDecoder, WeightedRCQDecoder, NonUniformQuantizer\n"
+         "from training_framework import TrainingConfig, PosteriorJointTrainer, GradientExplosionAnalyzer, create_dvbs2_code\n"
+         "from simulation_framework import SimulationConfig, LDPSimulator, create_test_decoders\n"
+         "from ldpc_decoder import LDPCCode, simulate_awgn_channel\n"
+         "from rcq_decoder import WeightedRCQDecoder\n", ns)
+    code = ns["create_dvbs2_code"]()
+    assert (code.n, code.k, code.max_iterations) == (16200, 7200, 50) and code.H.shape == (9000, 16200)
+    # the reference's ldpc_decoder module carries its own NeuralMinSumDecoder (:155): weights randn*0.1, no +0.7
+    import ldpc_decoder
+    import neural_minsum_decoder
+    toy = ns["create_test_ldpc_code"]()
+    torch.manual_seed(3)
+    a = ldpc_decoder.NeuralMinSumDecoder(toy, max_iterations=2)
+    torch.manual_seed(3)
+    b = neural_minsum_decoder.NeuralMinSumDecoder(toy, max_iterations=2)
+    assert type(a).__name__ == "NeuralMinSumDecoder" and len(a.alpha_weights) == 0
+    assert list(a.beta_weights.keys()) == list(b.beta_weights.keys()) and len(a.beta_weights) == 2 * 13
+    for k in a.beta_weights.keys():
+        assert b.beta_weights[k].item() == pytest.approx(a.beta_weights[k].item() + 0.7, abs=1e-6)
