@@ -75,6 +75,8 @@ struct ldpc_graph {
     int device = 0;
     int n = 0, m = 0, E = 0, max_dc = 0, max_dv = 0;
     int *check_ptr = nullptr, *var_idx = nullptr, *var_ptr = nullptr, *csc_edge = nullptr;
+    int *wide_checks = nullptr;    // checks of degree > kWideCheck (cn_sweep_wide splits each over a block)
+    int n_wide = 0;
     std::vector<int> h_check_ptr, h_var_idx, h_var_ptr, h_csc, h_check_of_edge;   // host copies (resident-plan builder)
     GraphDev dev() const { return GraphDev{n, m, E, check_ptr, var_idx, var_ptr, csc_edge}; }
 };
@@ -178,6 +180,7 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     if (cb == 0 || g.E == 0) return LDPC_OK;
     const dim3 grid((unsigned)((size_t)w.tiles * cb)), block(kBlock);
     const bool first = it == 0;
+    const int n_wide = d->g->n_wide;                 // > 0: the sweep below skips them, cn_sweep_wide follows
     const T *src = first ? (const T *)w.llrT : (const T *)w.v2c;
     const T *beta_row = (const T *)d->beta + (size_t)it * d->n_beta;
     const T *oa_row = d->oms_alpha ? (const T *)d->oms_alpha + (size_t)it * d->n_oms_alpha : nullptr;
@@ -186,7 +189,7 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
 #define LDPC_CN_X(FORM, FIRST, NL_, BPC_, CPW_)                                                                       \
     hipLaunchKernelGGL((cn_sweep<T, VEC, FORM, FIRST, NL_, BPC_, CPW_>), grid, block, 0, s, g, src, (void *)w.c2v,    \
                        beta_row, d->beta_slot, thr, d->n_levels, oa_row, d->oms_alpha_slot, done, cb,             \
-                       (const void *)w.c2v_prev)
+                       (const void *)w.c2v_prev, n_wide)
 #define LDPC_CN(FORM, FIRST) LDPC_CN_X(FORM, FIRST, 0, false, 1)
     if (d->form == LDPC_C2V_NMS) {
         if (cpw == 2) { if (first) LDPC_CN_X(FORM_NMS, true, 0, false, 2); else LDPC_CN_X(FORM_NMS, false, 0, false, 2); }
@@ -217,6 +220,23 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
 #undef LDPC_CN_X
 #undef LDPC_CN
     HIP_TRY(hipGetLastError());
+    if (n_wide) {
+        const dim3 wgrid((unsigned)((size_t)w.tiles * n_wide));
+#define LDPC_CW(FORM, FIRST, NL_)                                                                                     \
+    hipLaunchKernelGGL((cn_sweep_wide<T, VEC, FORM, FIRST, NL_>), wgrid, block, 0, s, g, (const int *)d->g->wide_checks, \
+                       n_wide, src, (void *)w.c2v, beta_row, d->beta_slot, thr, d->n_levels, oa_row,                  \
+                       d->oms_alpha_slot, done, (const void *)w.c2v_prev)
+        if (d->form == LDPC_C2V_NMS) { if (first) LDPC_CW(FORM_NMS, true, 0); else LDPC_CW(FORM_NMS, false, 0); }
+        else if (d->form == LDPC_C2V_OMS) { if (first) LDPC_CW(FORM_OMS, true, 0); else LDPC_CW(FORM_OMS, false, 0); }
+        else {
+            if constexpr (sizeof(T) == 4) {
+                if (d->n_levels == 4) { if (first) LDPC_CW(FORM_RCQ, true, 4); else LDPC_CW(FORM_RCQ, false, 4); }
+                else { if (first) LDPC_CW(FORM_RCQ, true, 0); else LDPC_CW(FORM_RCQ, false, 0); }
+            }
+        }
+#undef LDPC_CW
+        HIP_TRY(hipGetLastError());
+    }
     return LDPC_OK;
 }
 
@@ -478,6 +498,8 @@ void resident_table_flags(ldpc_decoder *d, const void *alpha_host, const float *
 
 // ---- LDS-resident engine: plan (host) ---------------------------------------------------------
 constexpr size_t kLdsBytes = 160 * 1024;          // LDS per CU; one workgroup may take all of it
+constexpr int kResSubDegreeCap = 32;              // checks up to this degree stay whole in the resident engine ...
+constexpr int kResSubDegree = 16;                 // ... wider ones are split into lane groups of sub-checks this long
 
 template <typename X>
 int plan_upload(ldpc_decoder *d, const X **dst, const std::vector<X> &src)
@@ -581,13 +603,45 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
 {
     const ldpc_graph *g = d->g;
     d->res_ok = false;
-    if (g->E == 0 || g->max_dc > 32 || g->max_dv > 8) return LDPC_OK;
+    if (g->E == 0 || g->max_dv > 8) return LDPC_OK;
     // fp64 (the reference's BasicMinSumDecoder dtype): the normalised form with one factor per check; a codeword's
     // 8-byte slots take the place of a float codeword PAIR, so the geometry below must come out at G = 2
     const bool f64 = d->dtype == LDPC_F64;
     if (f64 && (d->form != LDPC_C2V_NMS || !d->beta_per_check)) return LDPC_OK;
-    const int n = g->n, m = g->m;
+    const int n = g->n;
     if (n > 65535 || d->n_beta > 65535 || d->n_alpha >= (1 << 24) || d->n_oms_alpha > 65535) return LDPC_OK;
+
+    // Lane positions of the check phase are VIRTUAL checks.  A check of degree <= kResSubDegreeCap is one of them; a wider
+    // one is split into 2^k sub-checks of contiguous edges (balanced, at most kResSubDegree each) that sit on ADJACENT lanes
+    // and are combined by wavefront exchanges (ldpc_resident.hip: group_combine).  Groups come first, by descending size --
+    // every group then starts at a multiple of its size, so it never straddles a wave -- then the whole checks.
+    struct VCheck { int check, e0, dc, gs; };
+    std::vector<VCheck> vc;
+    {
+        auto dc_real = [&](int i) { return g->h_check_ptr[i + 1] - g->h_check_ptr[i]; };
+        std::vector<int> wide_ids, plain_ids;
+        for (int i = 0; i < g->m; ++i) (dc_real(i) > kResSubDegreeCap ? wide_ids : plain_ids).push_back(i);
+        auto group_of = [&](int i) { int k = 1; while (k * kResSubDegree < dc_real(i)) k <<= 1; return k; };
+        for (int i : wide_ids)
+            if (group_of(i) > 64) return LDPC_OK;                 // wider than a wavefront of sub-checks
+        std::stable_sort(wide_ids.begin(), wide_ids.end(), [&](int a, int b) { return group_of(a) > group_of(b); });
+        for (int i : wide_ids) {
+            const int k = group_of(i), dc = dc_real(i), base = dc / k, rem = dc % k;
+            int e = g->h_check_ptr[i];
+            for (int j = 0; j < k; ++j) {
+                const int len = base + (j < rem ? 1 : 0);
+                vc.push_back({i, e, len, k});
+                e += len;
+            }
+        }
+        std::stable_sort(plain_ids.begin(), plain_ids.end(), [&](int a, int b) { return dc_real(a) > dc_real(b); });
+        for (int i : plain_ids) vc.push_back({i, g->h_check_ptr[i], dc_real(i), 1});
+    }
+    const int m = (int)vc.size();
+    const bool any_split = m != g->m;
+    int max_sub = 0;
+    for (const VCheck &v : vc) max_sub = std::max(max_sub, v.dc);
+    if (m > 65535 || max_sub > 255) return LDPC_OK;
 
     // geometry: G codewords per workgroup, NT threads, and the row stride of the slot layout.
     // Two 512-thread workgroups per CU (G = 2, ds_read/write_b64) let one workgroup's barrier wait overlap
@@ -596,7 +650,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     // immediate offset; it is taken when it costs neither G nor workgroups per CU.
     // LDPC_RESIDENT_G / _NT override for tuning (read only by -DLDPC_RESIDENT_PROBES builds).
     auto geometry = [&](int stride, int &G_out, int &blocks_out) {
-        const long long S_ = (long long)g->max_dc * stride;
+        const long long S_ = (long long)max_sub * stride;
         if (S_ > 65535 || !resident_fits(d, S_, 1, 1)) return false;
         int G_ = 0;
 #ifdef LDPC_RESIDENT_PROBES
@@ -616,52 +670,48 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
         int G5 = 0, b5 = 0;
         if (geometry(512, G5, b5) && G5 == G && std::min(b5, 2) == std::min(blocks, 2)) { mstride = 512; blocks = b5; }
     }
-    const long long S = (long long)g->max_dc * mstride;
+    const long long S = (long long)max_sub * mstride;
     int NT = 0;
 #ifdef LDPC_RESIDENT_PROBES
     { const char *en = getenv("LDPC_RESIDENT_NT"); if (en) NT = atoi(en); }
 #endif
     if (NT < 64 || NT > 1024 || NT % 64) NT = blocks >= 2 ? 512 : 1024;
 
-    std::vector<int> perm_c(m), perm_v(n), pos_c(m), pos_v(n);
-    for (int i = 0; i < m; ++i) perm_c[i] = i;
+    std::vector<int> perm_v(n), pos_v(n);
     for (int j = 0; j < n; ++j) perm_v[j] = j;
-    auto dc_of = [&](int i) { return g->h_check_ptr[i + 1] - g->h_check_ptr[i]; };
     auto dv_of = [&](int j) { return g->h_var_ptr[j + 1] - g->h_var_ptr[j]; };
-    std::stable_sort(perm_c.begin(), perm_c.end(), [&](int a, int b) { return dc_of(a) > dc_of(b); });
     std::stable_sort(perm_v.begin(), perm_v.end(), [&](int a, int b) { return dv_of(a) > dv_of(b); });
-    for (int p = 0; p < m; ++p) pos_c[perm_c[p]] = p;
+    std::vector<int> slot_of_edge(g->E);
+    for (int p = 0; p < m; ++p)
+        for (int t = 0; t < vc[p].dc; ++t) slot_of_edge[vc[p].e0 + t] = t * mstride + p;
     {   // slots are fixed by the check order alone; choose the variable order inside each degree class
         std::vector<std::vector<int>> vs(n);
         for (int j = 0; j < n; ++j)
-            for (int k = 0; k < dv_of(j); ++k) {
-                const int e = g->h_csc[g->h_var_ptr[j] + k], i = g->h_check_of_edge[e];
-                vs[j].push_back((e - g->h_check_ptr[i]) * mstride + pos_c[i]);
-            }
+            for (int k = 0; k < dv_of(j); ++k) vs[j].push_back(slot_of_edge[g->h_csc[g->h_var_ptr[j] + k]]);
         optimise_lane_order(perm_v, vs, G);
     }
     for (int q = 0; q < n; ++q) pos_v[perm_v[q]] = q;
 
-    std::vector<uint8_t> dc_s(m);
+    std::vector<uint8_t> dc_s(m), gsz(m);
     std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0), inv(n);
     std::vector<uint32_t> vmeta(n);
     std::vector<uint4> vslot_lo(n), vslot_hi(n);
-    std::vector<int> slot_of_edge(g->E);
     std::vector<uint32_t> edge_of_slot((size_t)S, 0xffffffffu);
     bool per_check = true;
     for (int p = 0; p < m; ++p) {
-        const int i = perm_c[p], e0 = g->h_check_ptr[i], dc = dc_of(i);
-        dc_s[p] = (uint8_t)dc;
-        for (int t = 0; t < dc; ++t) {
-            const int e = e0 + t, slot = t * mstride + p;
-            slot_of_edge[e] = slot;
+        const VCheck &v = vc[p];
+        const int first = g->h_check_ptr[v.check];                  // the WHOLE check's first edge decides "one beta per check"
+        dc_s[p] = (uint8_t)v.dc;
+        gsz[p] = (uint8_t)v.gs;
+        for (int t = 0; t < v.dc; ++t) {
+            const int e = v.e0 + t, slot = t * mstride + p;
             edge_of_slot[slot] = (uint32_t)e;
             cvar[slot] = (uint16_t)pos_v[g->h_var_idx[e]];
             bslot[slot] = (uint16_t)desc->beta_slot[e];
-            if (desc->beta_slot[e] != desc->beta_slot[e0]) per_check = false;
+            if (desc->beta_slot[e] != desc->beta_slot[first]) per_check = false;
             if (d->form == LDPC_C2V_OMS && desc->oms_alpha) oaslot[slot] = (uint16_t)desc->oms_alpha_slot[e];
         }
-        bslot_c[p] = dc ? (uint16_t)desc->beta_slot[e0] : 0;
+        bslot_c[p] = v.dc ? (uint16_t)desc->beta_slot[first] : 0;
     }
     for (int q = 0; q < n; ++q) {
         const int j = perm_v[q], s0 = g->h_var_ptr[j], dv = dv_of(j);
@@ -674,8 +724,10 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     }
     ResidentPlan &pl = d->res;
     pl = ResidentPlan{};
-    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = g->max_dc; pl.max_dv = g->max_dv; pl.mstride = mstride; pl.E = g->E;
+    pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = max_sub; pl.max_dv = g->max_dv; pl.mstride = mstride; pl.E = g->E;
+    pl.any_split = any_split ? 1 : 0;
     int rc = plan_upload(d, &pl.dc_s, dc_s);
+    if (!rc && any_split) rc = plan_upload(d, &pl.gsz, gsz);
     if (!rc) rc = plan_upload(d, &pl.cvar, cvar);
     if (!rc) rc = plan_upload(d, &pl.bslot, bslot);
     if (!rc && per_check) rc = plan_upload(d, &pl.bslot_c, bslot_c);
@@ -713,14 +765,17 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
     if (d->dtype == LDPC_F64) {                       // one fp64 codeword per workgroup in the slots of a float pair
         if (G != 2 || !d->res.bslot_c) return fail(LDPC_ERR_ARG, "internal: fp64 resident geometry");
         const unsigned blocks64 = (unsigned)a.batch;
-#define LDPC_RES64(MS)                                                                                    \
+#define LDPC_RES64(MS, SPLIT)                                                                             \
     do {                                                                                                  \
-        auto kfn = a.early_stop ? resident_decode<1, FORM_NMS, true, 0, MS, 1, double>                    \
-                                : resident_decode<1, FORM_NMS, true, 0, MS, 0, double>;                   \
-        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                      \
+        auto kfn = a.early_stop ? resident_decode<1, FORM_NMS, true, 0, MS, 1, double, SPLIT>             \
+                                : resident_decode<1, FORM_NMS, true, 0, MS, 0, double, SPLIT>;            \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                        \
         hipLaunchKernelGGL(kfn, dim3(blocks64), dim3(d->res_NT), lds, s, d->res, a);                      \
     } while (0)
-        if (d->res.mstride == 512) LDPC_RES64(512); else LDPC_RES64(0);
+        // codes with split (wide) checks run the generic-stride instantiation with the lane-group exchange compiled in
+        if (d->res.any_split) LDPC_RES64(0, true);
+        else if (d->res.mstride == 512) LDPC_RES64(512, false);
+        else LDPC_RES64(0, false);
 #undef LDPC_RES64
         HIP_TRY(hipGetLastError());
         return LDPC_OK;
@@ -729,16 +784,22 @@ int launch_resident(const ldpc_decoder *d, const ResidentArgs &a, hipStream_t s)
 #ifdef LDPC_RESIDENT_PROBES
     { const char *pad = getenv("LDPC_RES_LDS_PAD"); if (pad && atoi(pad) > 0) lds = std::min<size_t>(lds + atoi(pad), 160 * 1024); }  // occupancy experiments
 #endif
-#define LDPC_RES_MS(FORM, NL, MS)                                                                        \
+#define LDPC_RES_MS(FORM, NL, MS, SPLIT)                                                                 \
     do {                                                                                                 \
-        auto kfn = d->res.bslot_c ? (a.early_stop ? resident_decode<G, FORM, true, NL, MS, 1> : resident_decode<G, FORM, true, NL, MS, 0>)   \
-                                  : (a.early_stop ? resident_decode<G, FORM, false, NL, MS, 1> : resident_decode<G, FORM, false, NL, MS, 0>); \
-        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                     \
+        auto kfn = d->res.bslot_c ? (a.early_stop ? resident_decode<G, FORM, true, NL, MS, 1, float, SPLIT>     \
+                                                  : resident_decode<G, FORM, true, NL, MS, 0, float, SPLIT>)    \
+                                  : (a.early_stop ? resident_decode<G, FORM, false, NL, MS, 1, float, SPLIT>    \
+                                                  : resident_decode<G, FORM, false, NL, MS, 0, float, SPLIT>);  \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                       \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(d->res_NT), lds, s, d->res, a);                       \
     } while (0)
+    // codes with split (wide) checks: the generic instantiation (run-time stride and level count) with the lane-group
+    // exchange compiled in -- the specialised ones stay exactly as lean as without the feature
 #define LDPC_RES(FORM, NL)                                                                               \
     do {                                                                                                 \
-        if (d->res.mstride == 512) LDPC_RES_MS(FORM, NL, 512); else LDPC_RES_MS(FORM, NL, 0);            \
+        if (d->res.any_split) LDPC_RES_MS(FORM, 0, 0, true);                                             \
+        else if (d->res.mstride == 512) LDPC_RES_MS(FORM, NL, 512, false);                               \
+        else LDPC_RES_MS(FORM, NL, 0, false);                                                            \
     } while (0)
     if (d->form == LDPC_C2V_NMS) LDPC_RES(FORM_NMS, 0);
     else if (d->form == LDPC_C2V_OMS) LDPC_RES(FORM_OMS, 0);
@@ -845,6 +906,14 @@ static int graph_create_impl(ldpc_graph **out, int32_t n, int32_t m, int32_t E, 
     if (!rc) rc = upload(&g->var_idx, var_idx, (size_t)E);
     if (!rc) rc = upload(&g->var_ptr, var_ptr.data(), (size_t)n + 1);
     if (!rc) rc = upload(&g->csc_edge, csc.data(), (size_t)E);
+    std::vector<int> wide;
+    for (int i = 0; i < m; ++i)
+        if (check_ptr[i + 1] - check_ptr[i] > kWideCheck) wide.push_back(i);
+#ifdef LDPC_NO_WIDE_KERNEL                            // A/B timing builds of tools/time_wide.py only
+    wide.clear();
+#endif
+    g->n_wide = (int)wide.size();
+    if (!rc && g->n_wide) rc = upload(&g->wide_checks, wide.data(), wide.size());
     if (rc) {
         ldpc_graph_destroy(g);
         return rc;
@@ -864,6 +933,7 @@ void ldpc_graph_destroy(ldpc_graph *g)
     if (!g) return;
     DeviceGuard guard(g->device);
     (void)hipFree(g->check_ptr); (void)hipFree(g->var_idx); (void)hipFree(g->var_ptr); (void)hipFree(g->csc_edge);
+    (void)hipFree(g->wide_checks);
     delete g;
 }
 
@@ -1016,7 +1086,7 @@ int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
     if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_SWEEPS) return fail(LDPC_ERR_ARG, "bad mode");
     if (mode == LDPC_MODE_RESIDENT && !d->res_ok)
         return fail(LDPC_ERR_UNSUPPORTED, "code does not qualify for the LDS-resident engine "
-                                          "(fp32, dc <= 32, dv <= 8, state within 160 KiB of LDS)");
+                                          "(dv <= 8, check degree <= 1024, state within 160 KiB of LDS)");
     d->mode = mode;
     return LDPC_OK;
 }

@@ -24,6 +24,7 @@ namespace ldpc {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;                 // 4 waves: 4 consecutive nodes of one tile
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kWideCheck = 32;              // checks of higher degree go to cn_sweep_wide (one check per block)
 
 enum { FORM_NMS = 0, FORM_RCQ = 1, FORM_OMS = 2 };
 
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
                                                    const T *__restrict__ oms_alpha_row,
                                                    const int *__restrict__ oms_alpha_slot,
                                                    const uint64_t *__restrict__ done, int check_blocks,
-                                                   const void *__restrict__ prev_out = nullptr)
+                                                   const void *__restrict__ prev_out = nullptr, int skip_wide = 0)
 {
     constexpr int W = kWave * VEC;
     using OutT = typename std::conditional<FORM == FORM_RCQ, uint8_t, T>::type;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
     const int e0 = uni(g.check_ptr[i]);
     const int dc = uni(g.check_ptr[i + 1]) - e0;
     if (dc == 0) continue;
+    if (skip_wide && dc > kWideCheck) continue;    // wide checks are split over the waves of a block by cn_sweep_wide
     if (all_frozen) {                              // saving mode: carry the tile's latched rows into this slice
         const size_t off = ((size_t)tile * g.E + e0) * W + (size_t)lane * VEC;
         for (int t = 0; t < dc; ++t)
@@ -361,6 +363,157 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
         store_latched<OutT, VEC>(out_base + (size_t)t * W, prev_base ? prev_base + (size_t)t * W : nullptr, o, fz);
     }
     }   // checks of this wave
+}
+
+// ------------------------------------------------------------------------------------------
+// Check-node sweep for WIDE checks (degree > kWideCheck): lanes still run over codewords, but the check's edges are
+// split over the four waves of the block -- wave w streams the rows of its quarter, keeping min1 / min2 / first
+// arg-min / sign parity / zero count of that quarter; the partials meet in LDS, every wave combines the four in
+// edge order (so the first-minimum rule and the tie behaviour are those of one sequential scan) and emits its own
+// quarter.  A quarter of at most 32 edges keeps its sign / zero masks in registers: checks up to degree 128 are
+// read exactly once (the one-wave kernel re-reads every input row of a check wider than 32); beyond that a quarter
+// re-reads its rows in pass 2.  One block = one (tile, wide check).  Any C2V rule, same arithmetic as cn_sweep.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int FORM, bool FIRST, int NL = 0>
+__global__ __launch_bounds__(kBlock) void cn_sweep_wide(GraphDev g, const int *__restrict__ wide_checks, int n_wide,
+                                                        const T *__restrict__ src, void *__restrict__ c2v_out,
+                                                        const T *__restrict__ beta_row,
+                                                        const int *__restrict__ beta_slot,
+                                                        const float *__restrict__ thr, int n_levels,
+                                                        const T *__restrict__ oms_alpha_row,
+                                                        const int *__restrict__ oms_alpha_slot,
+                                                        const uint64_t *__restrict__ done,
+                                                        const void *__restrict__ prev_out)
+{
+    constexpr int W = kWave * VEC;
+    using OutT = typename std::conditional<FORM == FORM_RCQ, uint8_t, T>::type;
+    __shared__ T s_m1[kWavesPerBlock][W], s_m2[kWavesPerBlock][W];
+    __shared__ int s_idx[kWavesPerBlock][W];
+    __shared__ unsigned s_par[kWavesPerBlock][W], s_nz[kWavesPerBlock][W];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = uni(threadIdx.x >> 6);
+    const int tile = uni(blockIdx.x / n_wide);
+    const int i = uni(wide_checks[blockIdx.x % n_wide]);
+    const int e0 = uni(g.check_ptr[i]);
+    const int dc = uni(g.check_ptr[i + 1]) - e0;
+    const int quarter = (dc + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int t_beg = min(dc, wave * quarter), t_end = min(dc, t_beg + quarter);
+
+    Frozen<VEC> fz;
+    const bool all_frozen = load_frozen<VEC>(done, tile, lane, fz);      // tile-uniform: the whole block agrees
+    if (all_frozen && !prev_out) return;
+    const size_t lane_off = (size_t)lane * VEC;
+    OutT *out_base = reinterpret_cast<OutT *>(c2v_out) + ((size_t)tile * g.E + e0) * W + lane_off;
+    const OutT *prev_base = prev_out ? reinterpret_cast<const OutT *>(prev_out) + ((size_t)tile * g.E + e0) * W + lane_off : nullptr;
+    if (all_frozen) {                              // saving mode: carry the tile's latched rows into this slice
+        for (int t = t_beg; t < t_end; ++t)
+            st<OutT, VEC>(out_base + (size_t)t * W, ld<OutT, VEC>(prev_base + (size_t)t * W));
+        return;
+    }
+    float th[8];
+    if (FORM == FORM_RCQ) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
+    }
+    const T *in_base = FIRST ? src + (size_t)tile * g.n * W + lane_off : src + ((size_t)tile * g.E + e0) * W + lane_off;
+    auto row_of = [&](int t) { return FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W; };
+
+    T m1[VEC], m2[VEC];
+    int idx[VEC];
+    uint32_t sm[VEC], zm[VEC];
+    unsigned par[VEC], nz[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<T>(); m2[c] = inf_of<T>(); idx[c] = 0; sm[c] = 0; zm[c] = 0; par[c] = 0; nz[c] = 0; }
+#pragma unroll 4
+    for (int t = t_beg; t < t_end; ++t) {
+        const Pack<T, VEC> v = ld<T, VEC>(row_of(t));
+        const int k = (t - t_beg) & 31;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const T a = abs_of<T>(v.x[c]);
+            const unsigned sb = signbit_of<T>(v.x[c]);
+            par[c] ^= sb;
+            sm[c] |= sb << k;
+            if (FORM == FORM_OMS) {
+                const unsigned z = (a == (T)0) ? 1u : 0u;
+                nz[c] += z;
+                zm[c] |= z << k;
+            }
+            if (a < m1[c]) { m2[c] = m1[c]; m1[c] = a; idx[c] = t; }
+            else if (a < m2[c]) { m2[c] = a; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const int w = lane * VEC + c;
+        s_m1[wave][w] = m1[c]; s_m2[wave][w] = m2[c]; s_idx[wave][w] = idx[c]; s_par[wave][w] = par[c]; s_nz[wave][w] = nz[c];
+    }
+    __syncthreads();
+    // the four quarters in edge order: a strict "<" keeps the FIRST minimum, and a partial whose minimum is not
+    // smaller can only lower min2
+    T M1[VEC], M2[VEC];
+    int IDX[VEC];
+    unsigned PAR[VEC], NZ[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const int w = lane * VEC + c;
+        M1[c] = inf_of<T>(); M2[c] = inf_of<T>(); IDX[c] = 0; PAR[c] = 0; NZ[c] = 0;
+#pragma unroll
+        for (int q = 0; q < kWavesPerBlock; ++q) {
+            const T p1 = s_m1[q][w], p2 = s_m2[q][w];
+            if (p1 < M1[c]) {
+                M2[c] = M1[c] < p2 ? M1[c] : p2;
+                M1[c] = p1;
+                IDX[c] = s_idx[q][w];
+            } else {
+                M2[c] = p1 < M2[c] ? p1 : M2[c];
+            }
+            PAR[c] ^= s_par[q][w];
+            NZ[c] += s_nz[q][w];
+        }
+    }
+    const bool reread = (t_end - t_beg) > 32;      // this quarter's masks hold 32 edges
+#pragma unroll 2
+    for (int t = t_beg; t < t_end; ++t) {
+        const T b = beta_row[beta_slot[e0 + t]];
+        T oa = (T)0;
+        if (FORM == FORM_OMS && oms_alpha_row) oa = oms_alpha_row[oms_alpha_slot[e0 + t]];
+        Pack<T, VEC> re;
+        if (reread) re = ld<T, VEC>(row_of(t));
+        const int k = (t - t_beg) & 31;
+        Pack<OutT, VEC> o;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const T raw = (t == IDX[c]) ? M2[c] : M1[c];
+            const unsigned own = reread ? signbit_of<T>(re.x[c]) : ((sm[c] >> k) & 1u);
+            const unsigned neg = PAR[c] ^ own;
+            if (FORM == FORM_NMS) {
+                o.x[c] = (OutT)flip_sign<T>(b * raw, neg);
+            } else if (FORM == FORM_OMS) {
+                const unsigned ownz = reread ? ((re.x[c] == (T)0) ? 1u : 0u) : ((zm[c] >> k) & 1u);
+                const bool nonzero = (NZ[c] - ownz) == 0;         // no OTHER edge carries a zero
+                const T d = raw - b;
+                const T r = d > (T)0 ? d : (T)0;
+                const T val = r - oa;
+                o.x[c] = (OutT)(nonzero ? flip_sign<T>(val, neg) : (T)0);
+            } else {
+                const float w = flip_sign<float>((float)(b * raw), neg);
+                const float mag = __builtin_fabsf(w);
+                int lvl = 0;
+                if constexpr (NL > 0) {
+#pragma unroll
+                    for (int q = 1; q < NL; ++q) lvl = (mag >= th[q]) ? q : lvl;
+                } else if (n_levels <= 8) {
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) lvl = (mag >= th[q]) ? q : lvl;
+                } else {
+                    for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? q : lvl;
+                }
+                o.x[c] = (OutT)(((w < 0.0f) ? n_levels : 0) + lvl);
+            }
+        }
+        store_latched<OutT, VEC>(out_base + (size_t)t * W, prev_base ? prev_base + (size_t)t * W : nullptr, o, fz);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

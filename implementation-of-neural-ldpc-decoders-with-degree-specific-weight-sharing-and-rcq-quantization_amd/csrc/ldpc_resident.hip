@@ -37,7 +37,10 @@ struct ResidentPlan {
     int mstride;                  // slots between consecutive edges of a check: slot(p,t) = t*mstride + p
                                   // (512 when m <= 512 so that LDS instructions can carry t*stride as an
                                   //  immediate offset; else m)
-    const uint8_t *dc_s;          // [m]          degree of the check at sorted position p
+    const uint8_t *dc_s;          // [m]          degree of the (sub-)check at sorted position p
+    const uint8_t *gsz;           // [m] or null  lane-group size of position p: a check wider than the slot layout admits is
+                                  //              split over 2^k ADJACENT lanes (sub-checks of contiguous edges); 1 = whole check
+    int any_split;                // some check is split (gsz != null): the host launches the SPLIT instantiation of the kernel
     const uint16_t *cvar;         // [max_dc*m]   sorted position of the variable of edge (p,t)
     const uint16_t *bslot;        // [max_dc*m]   beta table column of edge (p,t)
     const uint16_t *bslot_c;      // [m] or null: column shared by all edges of check p (Basic, RCQ,
@@ -70,6 +73,15 @@ struct ResidentArgs {
 };
 
 constexpr int kResAlphaMax = 1024;   // floats of alpha table kept in LDS
+constexpr int kResHeld = 16;         // check degrees up to this keep their values in registers between the two passes
+#ifndef LDPC_RES_CHECK_MODE
+#define LDPC_RES_CHECK_MODE 0        // 0 per-lane form only | 1 scalar form for single-degree waves | 2 one scalar pass per degree
+                                     // (measured on one box, (1998,1512) Basic / RCQ: 0: 3.10 / 3.30 ms, 1: 3.13 / 3.33, 2: 3.20 / 3.48;
+                                     //  LDPC_RES_VAR_MODE 1 costs another 0.15-0.25 ms: DESIGN.md 5)
+#endif
+#ifndef LDPC_RES_VAR_MODE
+#define LDPC_RES_VAR_MODE 0          // 0 per-lane dispatch | 1 one scalar pass per distinct degree
+#endif
 
 #ifdef LDPC_RESIDENT_PROBES
 #define LDPC_PROBE(a, bit) ((a).debug_skip & (bit))
@@ -133,12 +145,134 @@ __device__ __forceinline__ float res_quant_rec(float mag, const float (&th)[8], 
     return rec;
 }
 
-template <int G, int FORM, bool BPC, bool UNI, int NL, int MS, typename T>
+// ---- wide checks: one check split over a group of 2^k adjacent lanes ---------------------------------------------
+// Each lane reduces its own edges (min1 / min2 / sign bits / zero count); the partials are combined across the group by
+// an XOR butterfly of wavefront exchanges -- ds_swizzle (bit-mask mode, no LDS memory touched) inside 32 lanes, a
+// cross-half shuffle for the last step -- after which every lane of the group holds the whole check's values and emits
+// its own edges.  Steps beyond a lane's own group size are exchanged too (the instruction is wave-wide) but not combined.
+template <int O>
+__device__ __forceinline__ unsigned lane_xchg(unsigned v)
+{
+    if constexpr (O < 32) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (O << 10) | 0x1f);
+    else return (unsigned)__shfl_xor((int)v, 32, 64);
+}
+template <int O> __device__ __forceinline__ float lane_xchg(float v) { return __uint_as_float(lane_xchg<O>(__float_as_uint(v))); }
+template <int O>
+__device__ __forceinline__ double lane_xchg(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = lane_xchg<O>((unsigned)u), hi = lane_xchg<O>((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int O, int G, typename T>
+__device__ __forceinline__ void group_step(int gs, T (&m1)[G], T (&m2)[G], unsigned (&sg)[G], unsigned (&nz)[G])
+{
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const T a1 = lane_xchg<O>(m1[g]), a2 = lane_xchg<O>(m2[g]);
+        const unsigned as = lane_xchg<O>(sg[g]), an = lane_xchg<O>(nz[g]);
+        if (O < gs) {
+            // second smallest of {m1, m2, a1, a2} = min(max(m1, a1), min(m2, a2)); ties keep min2 == min1
+            const T hi = m1[g] < a1 ? a1 : m1[g];
+            const T lo2 = m2[g] < a2 ? m2[g] : a2;
+            m2[g] = hi < lo2 ? hi : lo2;
+            m1[g] = m1[g] < a1 ? m1[g] : a1;
+            sg[g] ^= as;
+            nz[g] += an;
+        }
+    }
+}
+template <int G, typename T>
+__device__ __forceinline__ void group_combine(int gs, T (&m1)[G], T (&m2)[G], unsigned (&sg)[G], unsigned (&nz)[G])
+{
+    group_step<1, G, T>(gs, m1, m2, sg, nz);
+    group_step<2, G, T>(gs, m1, m2, sg, nz);
+    group_step<4, G, T>(gs, m1, m2, sg, nz);
+    group_step<8, G, T>(gs, m1, m2, sg, nz);
+    group_step<16, G, T>(gs, m1, m2, sg, nz);
+    group_step<32, G, T>(gs, m1, m2, sg, nz);
+}
+// parity words of the syndrome phases
+__device__ __forceinline__ unsigned group_xor(int gs, unsigned x)
+{
+    unsigned y;
+    y = lane_xchg<1>(x);  if (1 < gs) x ^= y;
+    y = lane_xchg<2>(x);  if (2 < gs) x ^= y;
+    y = lane_xchg<4>(x);  if (4 < gs) x ^= y;
+    y = lane_xchg<8>(x);  if (8 < gs) x ^= y;
+    y = lane_xchg<16>(x); if (16 < gs) x ^= y;
+    y = lane_xchg<32>(x); if (32 < gs) x ^= y;
+    return x;
+}
+
+// Check update of ONE degree, fully unrolled (fp32, one beta per check): the DC values are read once, stay in registers
+// for both passes and are written back in place -- one LDS read and one LDS write per edge instead of two reads and a
+// write, no load-to-use wait in the second pass, no loop control.  Entered through a scalar switch on the wave's degree.
+template <int G, int FORM, int NL, int DC>
+__device__ __forceinline__ void res_check_held(unsigned base, unsigned stride, float b_check, const float (&th)[8],
+                                               const float *__restrict__ thr, int n_levels)
+{
+    using P = Pack<float, G>;
+    P v[DC];
+#pragma unroll
+    for (int t = 0; t < DC; ++t) v[t] = lds_load<P>(base + t * stride);
+    float m1[G], m2[G];
+    uint32_t sacc[G];
+    float ninf = -inf_of<float>();
+    asm volatile("" : "+v"(ninf));                    // opaque to constant folding: min as ONE v_med3
+#pragma unroll
+    for (int g = 0; g < G; ++g) { m1[g] = inf_of<float>(); m2[g] = inf_of<float>(); sacc[g] = 0; }
+#pragma unroll
+    for (int t = 0; t < DC; ++t) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            sacc[g] ^= __float_as_uint(v[t].x[g]);
+            m2[g] = __builtin_amdgcn_fmed3f(__builtin_fabsf(v[t].x[g]), m1[g], m2[g]);
+            m1[g] = __builtin_amdgcn_fmed3f(__builtin_fabsf(v[t].x[g]), m1[g], ninf);
+        }
+    }
+    if (DC == 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) m2[g] = m1[g];     // "min2_val = min_val" for a degree-1 check
+    }
+    uint32_t o1[G], o2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float w1 = b_check * m1[g], w2 = b_check * m2[g];
+        if (FORM == FORM_RCQ) {
+            // value = (1 - 2*(w < 0)) * tau[level(|w|)]; with tau_0 == 0 a zero magnitude reconstructs to +-0, so
+            // applying the edge sign afterwards is value-identical to the reference's order
+            const float r1 = res_quant_rec<NL>(__builtin_fabsf(w1), th, thr, n_levels);
+            const float r2 = res_quant_rec<NL>(__builtin_fabsf(w2), th, thr, n_levels);
+            w1 = flip_sign<float>(r1, (w1 < 0.0f) ? 1u : 0u);
+            w2 = flip_sign<float>(r2, (w2 < 0.0f) ? 1u : 0u);
+        }
+        const uint32_t par = sacc[g] & 0x80000000u;
+        o1[g] = __float_as_uint(w1) ^ par;
+        o2[g] = __float_as_uint(w2) ^ par;
+        asm volatile("" : "+v"(o1[g]), "+v"(o2[g]));  // keep the two per-check values materialised (see the generic form)
+    }
+#pragma unroll
+    for (int t = 0; t < DC; ++t) {
+        P o;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t sel = (__builtin_fabsf(v[t].x[g]) == m1[g]) ? o2[g] : o1[g];
+            o.x[g] = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(v[t].x[g]), 0x80000000u, 0x78));
+        }
+        lds_store<P>(base + t * stride, o);
+    }
+}
+
+template <int G, int FORM, bool BPC, bool UNI, int NL, int MS, typename T, bool SPLIT = false>
 __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned char *smem, int p, int dc, int dcw,
                                                T b_check, const T *__restrict__ beta_row,
                                                const T *__restrict__ oa_row, const float (&th)[8],
-                                               const float *__restrict__ thr, int n_levels, bool rcq_zero0)
+                                               const float *__restrict__ thr, int n_levels, bool rcq_zero0, int gs = 1)
 {
+    // UNI: every lane of the wave has the degree dcw (scalar loops).  !UNI: per-lane degrees, and the lanes of a group
+    // (gs > 1) hold the pieces of ONE wide check: their partials are combined between the two passes.
     constexpr int kEl = G * (int)sizeof(T);
     const int trip = UNI ? dcw : dc;
     const unsigned stride = (MS > 0 ? (unsigned)MS : (unsigned)pl.mstride) * kEl;   // compile-time when MS > 0
@@ -163,10 +297,16 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
                 else if (a < m2[g]) { m2[g] = a; }
             }
         }
+        if constexpr (!UNI && SPLIT) {
+            unsigned nzd[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) nzd[g] = 0;
+            group_combine<G, T>(gs, m1, m2, par, nzd);
+        }
         T o1[G], o2[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (trip == 1) m2[g] = m1[g];                   // "min2_val = min_val" for a degree-1 check
+            if (trip == 1 && gs == 1) m2[g] = m1[g];        // "min2_val = min_val" for a degree-1 check
             o1[g] = flip_sign<T>(b_check * m1[g], par[g]);
             o2[g] = flip_sign<T>(b_check * m2[g], par[g]);
         }
@@ -192,6 +332,21 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
     for (int g = 0; g < G; ++g) {
         m1[g] = inf_of<float>(); m2[g] = inf_of<float>(); sacc[g] = 0; nz[g] = 0;
     }
+#if LDPC_RES_CHECK_MODE != 0
+    constexpr bool kPerCheck = BPC && (FORM == FORM_NMS || FORM == FORM_RCQ);
+    if (kPerCheck && UNI && trip <= kResHeld && (FORM == FORM_NMS || rcq_zero0)) {
+        // The common case -- one beta per check and a wave-uniform degree of at most kResHeld edges: one scalar jump
+        // into straight-line code for exactly that degree, the check's values held in registers between the passes.
+#define LDPC_RH(D) case D: res_check_held<G, FORM, NL, D>(base, stride, b_check, th, thr, n_levels); return;
+        switch (trip) {
+            LDPC_RH(1) LDPC_RH(2) LDPC_RH(3) LDPC_RH(4) LDPC_RH(5) LDPC_RH(6) LDPC_RH(7) LDPC_RH(8)
+            LDPC_RH(9) LDPC_RH(10) LDPC_RH(11) LDPC_RH(12) LDPC_RH(13) LDPC_RH(14) LDPC_RH(15) LDPC_RH(16)
+        default: return;                              // trip == 0: nothing to do
+        }
+#undef LDPC_RH
+    }
+#endif
+    // generic form (any degree, per-lane trip counts, per-edge beta, OMS): pass 1 streams the slots, pass 2 re-reads them
 #pragma unroll 4
     for (int t = 0; t < trip; ++t) {
         const P v = lds_load<P>(base + t * stride);
@@ -206,7 +361,8 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
                                                                            // canonicalise + v_min: 3 ops)
         }
     }
-    if (trip == 1) {
+    if constexpr (!UNI && SPLIT) group_combine<G, float>(gs, m1, m2, sacc, nz);
+    if (trip == 1 && gs == 1) {
 #pragma unroll
         for (int g = 0; g < G; ++g) m2[g] = m1[g];     // "min2_val = min_val" for a degree-1 check
     }
@@ -290,7 +446,7 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
 
 // `dc_pre` / `b_pre` are the first round's degree and per-check beta, fetched by the caller ahead of
 // the barrier so their global-memory latency is off the critical path.
-template <int G, int FORM, bool BPC, int NL, int MS, typename T>
+template <int G, int FORM, bool BPC, int NL, int MS, typename T, bool SPLIT>
 __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned char *smem,
                                                 const T *__restrict__ beta_row,
                                                 const T *__restrict__ oa_row,
@@ -309,13 +465,53 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
             dc = pl.dc_s[p];
             b_check = BPC ? beta_row[pl.bslot_c[p]] : (T)0;
         }
-        for (bool pending = true; pending;) {            // wave-uniform trip count per distinct degree (see res_var_phase)
-            const int dcw = __builtin_amdgcn_readfirstlane(dc);
-            if (dc == dcw) {
-                res_check_body<G, FORM, BPC, true, NL, MS, T>(pl, smem, p, dc, dcw, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
-                pending = false;
+        if constexpr (SPLIT) {
+            // a wave holding lane groups runs the per-lane form for all its lanes at once: the group exchange between the
+            // passes needs every lane of a group at the same point of the program
+            const int gs = pl.gsz[p];
+            if (__ballot(gs > 1) != 0ull) {
+                res_check_body<G, FORM, BPC, false, NL, MS, T, true>(pl, smem, p, dc, dc, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0, gs);
+                continue;
             }
         }
+#if LDPC_RES_CHECK_MODE == 2
+        // One pass per DISTINCT degree in the wave (nodes are sorted by degree: all but the class-boundary waves make one
+        // pass), each with a scalar trip count.  The loop itself is uniform -- it runs on the scalar mask of lanes not yet
+        // served, every lane stays in it -- and the degree is handed to the body as an opaque scalar copy made BEFORE the
+        // comparison: inside `if (dc == dcw)` the optimiser would otherwise substitute the per-lane dc for the scalar and
+        // turn the edge loops back into exec-masked vector loops.  (A `for (pending) { rfl; if (==) {...} }` waterfall is not
+        // safe here: with the readfirstlane hoisted, lanes of another degree would spin forever, which the optimiser is
+        // entitled to assume never happens -- it then drops the comparison and runs every lane with the first lane's degree.)
+        for (unsigned long long todo = __ballot(true); todo;) {
+            const int dcw = __builtin_amdgcn_readlane(dc, __ffsll((long long)todo) - 1);
+            int trip = dcw;
+            asm volatile("" : "+s"(trip));
+            const bool mine = dc == dcw;
+            if (mine)
+                res_check_body<G, FORM, BPC, true, NL, MS, T>(pl, smem, p, dc, trip, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+            todo &= ~__ballot(mine);
+        }
+#elif LDPC_RES_CHECK_MODE == 1
+        // A wave whose lanes all have one degree (nodes are sorted by degree: all but the class-boundary waves) runs the
+        // scalar form -- trip count in an SGPR, for the common forms straight-line code of exactly that degree with the
+        // values held in registers; a class-boundary wave runs the per-lane form once for all its lanes (exec-masked
+        // loops over per-lane trip counts).  The scalar is an opaque copy: were it derived from `dc` visibly, the optimiser
+        // would put the per-lane value back (it knows dc == dcw in that branch).
+        {
+            const int dcw = __builtin_amdgcn_readfirstlane(dc);
+            int trip = dcw;
+            asm volatile("" : "+s"(trip));
+            if (__ballot(dc != dcw) == 0ull)
+                res_check_body<G, FORM, BPC, true, NL, MS, T>(pl, smem, p, dc, trip, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+            else
+                res_check_body<G, FORM, BPC, false, NL, MS, T>(pl, smem, p, dc, dc, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+        }
+#else
+        // every lane runs the edge loops with ITS degree as trip count (exec-masked vector loops): one pass per wave
+        // whatever the mix of degrees.  Measured fastest (see LDPC_RES_CHECK_MODE above): the phase is bound by VALU issue
+        // -- six instructions per edge and codeword, which the scalar forms do not reduce -- not by loop control.
+        res_check_body<G, FORM, BPC, false, NL, MS, T>(pl, smem, p, dc, dc, b_check, beta_row, oa_row, th, thr, n_levels, rcq_zero0);
+#endif
     }
 }
 
@@ -434,19 +630,25 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
         if (MODE == 0 || MODE == 4) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
         // one scalar branch into the body of the wave's degree; a class-boundary wave (two or three degrees)
         // goes round once per distinct degree with the other lanes masked off
-        for (bool pending = true; pending;) {
-            const int dvw = __builtin_amdgcn_readfirstlane(dv);
-            if (dv == dvw) {
-                res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dvw, slo, shi, a, emask);
-                pending = false;
-            }
+#if LDPC_RES_VAR_MODE == 1
+        for (unsigned long long todo = __ballot(true); todo;) {      // uniform loop, scalar degree (see res_check_phase)
+            const int dvw = __builtin_amdgcn_readlane(dv, __ffsll((long long)todo) - 1);
+            int dsel = dvw;
+            asm volatile("" : "+s"(dsel));
+            const bool mine = dv == dvw;
+            if (mine) res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dsel, slo, shi, a, emask);
+            todo &= ~__ballot(mine);
         }
+#else
+        // every lane jumps to the compile-time body of ITS degree (exec-masked dispatch): one pass per wave whatever the mix
+        res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask);
+#endif
         q = qn; meta = metan; slo = slon; shi = shin;
     }
 }
 
 // H @ bits mod 2 per check from the hard-decision bytes; OR of all checks' parities -> *sh_unsat
-template <int G>
+template <int G, bool SPLIT>
 __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const uint8_t *__restrict__ bits_s,
                                                    unsigned *sh_unsat, int tid, int nt)
 {
@@ -461,13 +663,14 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
         } else {
             for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
         }
+        if constexpr (SPLIT) x = group_xor(pl.gsz[p], x);   // a split check's parity is the XOR over its lane group
         acc |= x;
     }
     if (acc) atomicOr(sh_unsat, acc);
 }
 
 // final syndrome of a fixed-T decode from the hard decisions res_var_body<MODE 8> left in the message slots
-template <int G, typename T>
+template <int G, typename T, bool SPLIT>
 __device__ __forceinline__ void res_syndrome_slots(const ResidentPlan &pl, unsigned *sh_unsat, int tid, int nt)
 {
     constexpr unsigned kSlot = sizeof(Pack<T, G>);
@@ -482,6 +685,7 @@ __device__ __forceinline__ void res_syndrome_slots(const ResidentPlan &pl, unsig
         } else {
             for (int t = 0; t < dc; ++t) x ^= lds_load<unsigned>((unsigned)(t * pl.mstride + p) * kSlot);
         }
+        if constexpr (SPLIT) x = group_xor(pl.gsz[p], x);
         acc |= x;
     }
     if (acc) atomicOr(sh_unsat, acc);
@@ -605,7 +809,7 @@ __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha
 
 // ES: 0 = fixed-iteration kernel, 1 = early-stop kernel (kept apart so that the fixed-T kernel does not carry
 // the posterior/syndrome/emit code of the stop rule: the extra code cost the hot loop ~4 % when merged)
-template <int G, int FORM, bool BPC, int NL, int MS, int ES, typename T = float>
+template <int G, int FORM, bool BPC, int NL, int MS, int ES, typename T = float, bool SPLIT = false>
 __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
@@ -708,7 +912,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         const T *alpha_lds = a.alpha_in_lds ? alpha_s + it * a.n_alpha : nullptr;
         const T *alpha_glb = g_alpha + (size_t)it * a.n_alpha;
         if (!LDPC_PROBE(a, 1))
-            res_check_phase<G, FORM, BPC, NL, MS, T>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, a.rcq_zero0 != 0,
+            res_check_phase<G, FORM, BPC, NL, MS, T, SPLIT>(pl, res_smem, beta_row, oa_row, thr, a.n_levels, a.rcq_zero0 != 0,
                                                   dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = g_beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
@@ -721,7 +925,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
             else if (a.unit_alpha) res_var_phase<G, 6, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
             else res_var_phase<G, 4, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
             __syncthreads();
-            res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
+            res_syndrome_phase<G, SPLIT>(pl, bits_s, sh_unsat, tid, nt);
             __syncthreads();
             const unsigned unsat = *sh_unsat;
             __syncthreads();
@@ -738,7 +942,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
         if (ES) {
             res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
             __syncthreads();
-            res_syndrome_phase<G>(pl, bits_s, sh_unsat, tid, nt);
+            res_syndrome_phase<G, SPLIT>(pl, bits_s, sh_unsat, tid, nt);
             __syncthreads();
             const unsigned unsat = *sh_unsat;
             __syncthreads();
@@ -783,7 +987,7 @@ __global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, Residen
     __syncthreads();
     unsigned unsat = kAll;
     if (!ES && !LDPC_PROBE(a, 8)) {                    // fixed-T mode: success = final syndrome is zero
-        res_syndrome_slots<G, T>(pl, sh_unsat, tid, nt);
+        res_syndrome_slots<G, T, SPLIT>(pl, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
     }

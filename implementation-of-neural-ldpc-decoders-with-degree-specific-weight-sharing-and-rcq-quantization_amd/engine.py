@@ -241,6 +241,63 @@ class DecodeEngine:
                                                 C.c_void_p(stream)), "ldpc_decode")
         return DecodeResult(bits, post, iters, succ.bool(), packed)
 
+    # ------------------------------------------------------------------ small host batches (the reference's call shape)
+    HOST_BATCH_MAX = 64
+
+    def decode_host(self, llr_host: torch.Tensor, *, early_stop: bool = True, want_posterior: bool = True):
+        """Decode a SMALL batch that lives in host memory (the reference's own call: one CPU vector in, CPU results out)
+        with one staged copy each way: pinned host buffers and device buffers are kept per engine, the LLRs go up in one
+        async copy, ldpc_decode writes bits / posterior / iterations / success into ONE device block, that block comes
+        back in one async copy, one stream synchronise.  -> (bits int32 [B, n], posterior | None, iterations int32 [B],
+        success bool [B]) as CPU tensors (fresh copies).  Guarded by a lock: the staging buffers are per engine."""
+        if llr_host.dim() != 2 or llr_host.shape[1] != self.graph.n or llr_host.shape[0] > self.HOST_BATCH_MAX:
+            raise ValueError(f"decode_host takes [B <= {self.HOST_BATCH_MAX}, {self.graph.n}] host tensors")
+        B, n = llr_host.shape
+        es = 4 if self.dtype == torch.float32 else 8
+        with self._ws_lock:
+            st = getattr(self, "_host_stage", None)
+            if st is None:
+                Bm = self.HOST_BATCH_MAX
+                o_bits, o_post = 0, Bm * n * 4
+                o_it = o_post + Bm * n * es
+                o_ok = o_it + Bm * 4
+                total = (o_ok + Bm + 255) // 256 * 256
+                st = {"h_in": torch.empty((Bm, n), dtype=self.dtype, pin_memory=True),
+                      "d_in": torch.empty((Bm, n), dtype=self.dtype, device=self.device),
+                      "d_out": torch.empty(total, dtype=torch.uint8, device=self.device),
+                      "h_out": torch.empty(total, dtype=torch.uint8, pin_memory=True),
+                      "off": (o_bits, o_post, o_it, o_ok), "ws": None}
+                self._host_stage = st
+            o_bits, o_post, o_it, o_ok = st["off"]
+            st["h_in"][:B].copy_(llr_host)
+            with torch.cuda.device(self.device):
+                stream = torch.cuda.current_stream(self.device)
+                st["d_in"][:B].copy_(st["h_in"][:B], non_blocking=True)
+                need = self.workspace_bytes(B)
+                if st["ws"] is None or st["ws"].numel() < need:
+                    st["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                base = st["d_out"].data_ptr()
+                nat.check(self._lib.ldpc_decode(self.handle, C.c_void_p(st["d_in"].data_ptr()), B, int(bool(early_stop)),
+                                                C.c_void_p(base + o_bits), C.c_void_p(base + o_post) if want_posterior else None,
+                                                C.c_void_p(base + o_it), C.c_void_p(base + o_ok), None,
+                                                C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),
+                                                C.c_void_p(stream.cuda_stream)), "ldpc_decode")
+                st["h_out"].copy_(st["d_out"], non_blocking=True)
+                stream.synchronize()
+            h = st["h_out"]
+            bits = h[o_bits:o_bits + B * n * 4].view(torch.int32).view(B, n).clone()
+            post = h[o_post:o_post + B * n * es].view(self.dtype).view(B, n).clone() if want_posterior else None
+            iters = h[o_it:o_it + B * 4].view(torch.int32).clone()
+            succ = h[o_ok:o_ok + B].clone().bool()
+        return bits, post, iters, succ
+
+    def decode_host_op(self, llr_host: torch.Tensor, *, early_stop: bool = True, want_posterior: bool = True) -> DecodeResult:
+        """decode_host() through ``torch.ops.ldpc.decode_host`` -> DecodeResult of CPU tensors"""
+        import torch_ops
+        bits, post, iters, succ = torch.ops.ldpc.decode_host(llr_host, torch_ops.engine_handle(self), bool(early_stop),
+                                                             bool(want_posterior))
+        return DecodeResult(bits, post if want_posterior else None, iters, succ, None)
+
     def decode_op(self, llr: torch.Tensor, *, early_stop: bool = True, want_posterior: bool = True,
                   want_packed: bool = False) -> DecodeResult:
         """decode() entered through the registered PyTorch operator ``torch.ops.ldpc.decode`` (torch_ops.py) --

@@ -141,7 +141,17 @@ class BasicMinSumDecoder:
         if kind == "np":
             dt = torch.float32 if x.dtype == np.float32 else torch.float64
             eng = self._engine(dt, device)
-            xd = torch.from_numpy(np.ascontiguousarray(x, dtype=eng.np_dtype)).to(eng.device)
+            xh = torch.from_numpy(np.ascontiguousarray(x, dtype=eng.np_dtype))
+            if xh.shape[0] <= eng.HOST_BATCH_MAX:
+                # the reference's call shape: host vector in, host results out -- one staged copy each way
+                # (torch.ops.ldpc.decode_host)
+                res = eng.decode_host_op(xh, early_stop=early_stop, want_posterior=False)
+                bits = res.bits.numpy().astype(np.int64)
+                succ, its = res.success.numpy(), res.iterations.numpy()
+                if single:
+                    return bits[0], bool(succ[0]), int(its[0])
+                return bits, succ, its
+            xd = xh.to(eng.device)
         else:
             dt = torch.float64 if x.dtype == torch.float64 else torch.float32
             eng = self._engine(dt, x.device if x.is_cuda else device)

@@ -109,6 +109,8 @@ class _DegreeSharedDecoder(nn.Module):
             raise TypeError("llr must be a torch.Tensor")   # the reference fails on numpy input too (llr.device)
         _, x, single = _as_batch(llr, self.code.n)
         eng = self._get_engine(x.device if x.is_cuda else device)
+        if not x.is_cuda and x.shape[0] <= eng.HOST_BATCH_MAX:       # the reference's call shape: torch.ops.ldpc.decode_host
+            return eng.decode_host_op(x.detach().to(torch.float32), early_stop=early_stop), single, llr.device
         xd = x.detach().to(device=eng.device, dtype=torch.float32)
         res = eng.decode_op(xd, early_stop=early_stop)            # torch.ops.ldpc.decode
         return res, single, llr.device

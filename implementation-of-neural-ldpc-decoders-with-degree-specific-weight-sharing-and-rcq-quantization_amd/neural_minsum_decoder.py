@@ -112,7 +112,10 @@ class _EdgeWeightDecoder(nn.Module):
             if single:
                 return bits[0].to(out_dev), post[0].to(out_dev), int(iters[0].item())
             return bits.to(out_dev), post.to(out_dev), iters.to(out_dev)
-        res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
+        if not x.is_cuda and x.shape[0] <= eng.HOST_BATCH_MAX:
+            res = eng.decode_host_op(x.detach().to(torch.float32), early_stop=early_stop)
+        else:
+            res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop)
         if single:
             return res.bits[0].to(out_dev), res.posterior[0].to(out_dev), int(res.iterations[0].item())
         return res.bits.to(out_dev), res.posterior.to(out_dev), res.iterations.to(out_dev)

@@ -158,8 +158,11 @@ class RCQMinSumDecoder:
             raise TypeError("llr must be a torch.Tensor")    # the reference needs llr.device as well
         _, x, single = _as_batch(llr, self.code.n)
         eng = self._get_engine(x.device if x.is_cuda else device)
-        res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop,
-                         want_posterior=False)
+        if not x.is_cuda and x.shape[0] <= eng.HOST_BATCH_MAX:       # the reference's call shape: torch.ops.ldpc.decode_host
+            res = eng.decode_host_op(x.detach().to(torch.float32), early_stop=early_stop, want_posterior=False)
+        else:
+            res = eng.decode_op(x.detach().to(device=eng.device, dtype=torch.float32), early_stop=early_stop,
+                                want_posterior=False)
         out_dev = llr.device
         if single:
             return res.bits[0].to(out_dev), bool(res.success[0].item()), int(res.iterations[0].item())

@@ -11,6 +11,10 @@ enter the C ABI of include/ldpc_hip.h (ldpc_decode / ldpc_decode_saving / ldpc_b
         -> (Tensor bits, Tensor posterior, Tensor iterations, Tensor success, Tensor packed_bits)
      every decoder family (the engine handle carries the descriptor: C2V rule, tables, quantisers);
      outputs that were not asked for come back as empty tensors.  No autograd (inference).
+  ldpc::decode_host(Tensor llr_cpu, int engine, bool early_stop, bool want_posterior)
+        -> (Tensor bits, Tensor posterior, Tensor iterations, Tensor success)      all on the CPU
+     the reference's own call shape (one vector, or a batch of at most 64, in host memory): one staged async copy
+     each way around the same ldpc_decode.
   ldpc::minsum_decode_train(Tensor llr, Tensor beta, Tensor alpha, int engine, bool early_stop, bool alpha_is_oms)
         -> (Tensor posterior, Tensor bits, Tensor iterations, Tensor saved)
      the same decode keeping every iteration's messages (`saved`) for the backward sweeps; differentiable in
@@ -81,6 +85,23 @@ def _(llr, engine, early_stop, want_posterior, want_packed):
             torch.empty((B, n), dtype=llr.dtype, device=dev) if want_posterior else torch.empty((0,), dtype=llr.dtype, device=dev),
             torch.empty((B,), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.bool, device=dev),
             torch.empty((B, (n + 7) // 8), dtype=torch.uint8, device=dev) if want_packed else torch.empty((0,), dtype=torch.uint8, device=dev))
+
+
+@torch.library.custom_op("ldpc::decode_host", mutates_args=())
+def decode_host(llr: Tensor, engine: int, early_stop: bool, want_posterior: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """the reference's call shape -- a small batch in HOST memory, results back in host memory -- through one staged
+    copy each way (engine.DecodeEngine.decode_host); still the GPU engine, there is no CPU arithmetic"""
+    eng = _engine(engine)
+    bits, post, iters, succ = eng.decode_host(llr.to(eng.dtype), early_stop=early_stop, want_posterior=want_posterior)
+    return bits, post if want_posterior else torch.empty((0,), dtype=eng.dtype), iters, succ
+
+
+@decode_host.register_fake
+def _(llr, engine, early_stop, want_posterior):
+    B, n = llr.shape
+    dt = _engine(engine).dtype
+    return (torch.empty((B, n), dtype=torch.int32), torch.empty((B, n), dtype=dt) if want_posterior else torch.empty((0,), dtype=dt),
+            torch.empty((B,), dtype=torch.int32), torch.empty((B,), dtype=torch.bool))
 
 
 # ------------------------------------------------------------------------------------------ training path

@@ -514,6 +514,126 @@ def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
     assert len(np.unique(oi)) >= 2                                          # early stop was exercised
 
 
+def wide_check_code():
+    """Checks far wider than a lane's slot row (degree 40, 64, 100, 33, 129) beside ordinary ones, variable degrees <= 8:
+    the resident engine splits each wide check over a group of adjacent lanes (wavefront exchanges between the two
+    passes), the streaming engine over the four waves of a block (partials through LDS).  Reference loop: any degree,
+    ldpc_decoder.py:91-120."""
+    from ldpc_decoder import LDPCCode
+    rng = np.random.default_rng(2024)
+    n, degs = 420, [129, 100, 64, 40, 33, 6, 6, 5, 7, 6, 6, 3, 1, 6, 6, 6, 16, 17, 32, 6, 6, 6, 6, 2]
+    H = np.zeros((len(degs), n), dtype=np.int64)
+    load = np.zeros(n, dtype=np.int64)
+    for i, dc in enumerate(degs):
+        free = np.flatnonzero(load < 8)
+        pick = rng.choice(free, size=dc, replace=False)
+        H[i, pick] = 1
+        load[pick] += 1
+    return LDPCCode(n=n, k=n - len(degs), H=H, max_iterations=8)
+
+
+@pytest.mark.parametrize("early_stop", [True, False])
+def test_wide_checks_split_over_lanes_and_waves(early_stop, gpu_device, oracle_mod, engine_mode):
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder, WeightedRCQDecoder
+    code = wide_check_code()
+    og = oracle_mod.OracleGraph(code.H)
+    assert og.dc.max() == 129 and og.dv.max() <= 8
+    rng = np.random.default_rng(5)
+    B, T = 150, 8
+    llr64 = rng.standard_normal((B, code.n)) * 2.5 + 1.2
+    llr64[3, 7] = 0.0                                     # an exact zero inside a wide check (zero-aware OMS sign rule)
+    llr64[5] = np.round(llr64[5])                         # ties
+    llr = llr64.astype(np.float32)
+    x = torch.from_numpy(llr).to(gpu_device)
+
+    dec = BasicMinSumDecoder(code)
+    if engine_mode == "auto":
+        assert dec._engine(torch.float32, gpu_device).info()["engine"] == "resident"      # wide checks are admitted now
+    for arr, dt in ((llr64, np.float64), (llr, np.float32)):
+        bits, succ, iters = dec.decode(arr, early_stop=early_stop)
+        ob, op, oi, os_ = oracle_mod.basic_minsum(og, arr, 0.7, T, early_stop=early_stop, dtype=dt)
+        np.testing.assert_array_equal(iters, oi)
+        np.testing.assert_array_equal(succ, os_)
+        np.testing.assert_array_equal(bits, ob)
+
+    for wtype in (1, 2):
+        dec = Neural2DMinSumDecoder(code, weight_sharing_type=wtype, max_iterations=T)
+        beta, alpha = rand_weights(dec, rng)
+        bits, post, iters = dec(x, early_stop=early_stop)
+        ob, op, oi, _ = oracle_mod.neural2d(og, llr, wtype, T, beta, alpha, early_stop=early_stop)
+        np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+        np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+        assert_post(post.cpu().numpy(), op)
+
+    dec = Neural2DOffsetMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+    with torch.no_grad():
+        for p_ in dec.beta_weights.values():
+            p_.fill_(float(np.float32(rng.uniform(0.0, 0.4))))
+        for p_ in dec.alpha_weights.values():
+            p_.fill_(float(np.float32(rng.uniform(0.0, 0.1))))
+    beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+    alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+    bits, post, iters = dec(x, early_stop=early_stop)
+    ob, op, oi, _ = oracle_mod.neural2d_offset(og, llr, 2, T, beta, alpha, early_stop=early_stop)
+    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    assert_post(post.cpu().numpy(), op)
+
+    dec = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=T)
+    bits, succ, iters = dec.decode(x, early_stop=early_stop)
+    ob, op, oi, os_, oc = oracle_mod.rcq(og, llr, 3, QP, T, early_stop=early_stop, trace_codes=True)
+    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+    np.testing.assert_array_equal(succ.cpu().numpy(), os_)
+    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    assert_codes(codes_of(dec, x, early_stop), final_codes(oc, oi), 4)
+
+    dec = WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=1, max_iterations=T)      # per-(dc,dv) beta: per-edge path
+    beta, alpha = rand_weights(dec, rng)
+    bits, post, iters = dec(x, early_stop=early_stop)
+    ob, op, oi, _, oc = oracle_mod.weighted_rcq(og, llr, 3, QP, 1, T, beta, alpha, early_stop=early_stop, trace_codes=True)
+    np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+    np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+    np.testing.assert_array_equal(post.cpu().numpy(), op)
+    assert_codes(codes_of(dec, x, early_stop), final_codes(oc, oi), 4)
+
+
+@pytest.mark.parametrize("B", [1, 3, 64, 65])
+def test_host_batches_take_the_staged_path_with_identical_results(B, gpu_device):
+    """CPU inputs of at most 64 codewords (the reference's call shape) go through torch.ops.ldpc.decode_host -- one staged
+    copy each way -- and give exactly what the device-resident path gives; larger host batches take the ordinary path"""
+    import codes
+    import torch_ops
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder
+    code = codes.load_code("small_96_48", 8)
+    rng = np.random.default_rng(B)
+    llr = (rng.standard_normal((B, code.n)) * 2.0 + 1.5).astype(np.float32)
+    x = torch.from_numpy(llr)
+    n2d = Neural2DMinSumDecoder(code, 2, 8)
+    rand_weights(n2d, rng)
+    b_h, p_h, i_h = n2d(x)
+    b_d, p_d, i_d = n2d(x.to(gpu_device))
+    assert b_h.device.type == "cpu" and p_h.device.type == "cpu"
+    assert torch.equal(b_h, b_d.cpu()) and torch.equal(p_h, p_d.cpu()) and torch.equal(i_h, i_d.cpu())
+    rcq = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=8)
+    b_h, s_h, i_h = rcq.decode(x)
+    b_d, s_d, i_d = rcq.decode(x.to(gpu_device))
+    assert torch.equal(b_h, b_d.cpu()) and torch.equal(s_h, s_d.cpu()) and torch.equal(i_h, i_d.cpu())
+    bas = BasicMinSumDecoder(code)
+    for arr in (llr, llr.astype(np.float64)):
+        b_h, s_h, i_h = bas.decode(arr)
+        b_d, s_d, i_d = bas.decode(torch.from_numpy(arr).to(gpu_device))
+        np.testing.assert_array_equal(b_h, b_d.cpu().numpy())
+        np.testing.assert_array_equal(s_h, s_d.cpu().numpy())
+        np.testing.assert_array_equal(i_h, i_d.cpu().numpy())
+    if B <= 64:
+        h = torch_ops.engine_handle(n2d._get_engine(gpu_device))
+        torch.library.opcheck(torch.ops.ldpc.decode_host, (x, h, True, True))
+
+
 def sparse_odd_code():
     """14x40 sparse code that QUALIFIES for the LDS-resident engine (dc <= 32, dv <= 8) and still has a
     degree-1 check, an empty check, an isolated variable and a degree-1 variable"""

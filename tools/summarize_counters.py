@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""gpurun_out/counters/p*/ (tools/resident_counters.sh) -> profiles/<tag>_resident_counters.csv: per-launch averages of the
-SQ / LDS counters of ldpc::resident_decode plus a few derived ratios."""
+"""gpurun_out/<tag>/ctr_<workload>_p*/ (tools/gpu_round.sh) -> profiles/<tag>_<name>_counters.csv: per-launch averages of the
+SQ / LDS counters of one kernel plus a few derived ratios.
+
+    python tools/summarize_counters.py <tag> <workload> <kernel substring> <name>
+    e.g. r02 basic resident_decode resident   |   r02 wrcq_dvbs2 cn_gather gather"""
 import collections, csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+tag, workload, kernel, name = sys.argv[1:5]
 agg = collections.defaultdict(list)
-for f in glob.glob(os.path.join(ROOT, "gpurun_out", "counters", "p*", "**", "*counter_collection.csv"), recursive=True):
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", tag, f"ctr_{workload}_p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "resident_decode" in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in agg.items()}
 d = dict(avg)
@@ -19,7 +22,7 @@ if "SQ_LDS_IDX_ACTIVE" in avg and "SQ_LDS_BANK_CONFLICT" in avg:
     d["derived_lds_conflict_share_of_lds_cycles"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
 if "SQ_WAIT_ANY" in avg and "SQ_WAVE_CYCLES" in avg:
     d["derived_wait_share_of_wave_cycles"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
-out = os.path.join(ROOT, "profiles", f"{tag}_resident_counters.csv")
+out = os.path.join(ROOT, "profiles", f"{tag}_{name}_counters.csv")
 with open(out, "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["counter", "average_per_launch"])
