@@ -809,8 +809,12 @@ __host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha
 
 // ES: 0 = fixed-iteration kernel, 1 = early-stop kernel (kept apart so that the fixed-T kernel does not carry
 // the posterior/syndrome/emit code of the stop rule: the extra code cost the hot loop ~4 % when merged)
+#ifndef LDPC_RES_MAX_THREADS
+#define LDPC_RES_MAX_THREADS 1024      // launch bounds of resident_decode: threads per workgroup, waves per SIMD the
+#define LDPC_RES_MIN_WAVES 4           // register allocation must leave room for (tuning builds trade registers for waves)
+#endif
 template <int G, int FORM, bool BPC, int NL, int MS, int ES, typename T = float, bool SPLIT = false>
-__global__ __launch_bounds__(1024) void resident_decode(ResidentPlan pl, ResidentArgs a)
+__global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resident_decode(ResidentPlan pl, ResidentArgs a)
 {
     extern __shared__ __align__(16) unsigned char res_smem[];     // the only LDS object: msg starts at offset 0
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // lds_load/lds_store rely on that (folds away)
