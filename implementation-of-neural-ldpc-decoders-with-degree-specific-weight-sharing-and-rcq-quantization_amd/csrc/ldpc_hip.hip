@@ -124,7 +124,7 @@ bool use_gather(const ldpc_decoder *d) { return d->gat_ok && d->mode != LDPC_MOD
 int pick_vec(const ldpc_decoder *d, int64_t batch)
 {
     if (batch <= 64) return 1;
-    if (d->schedule == LDPC_SCHED_LAYERED_REF) return 1;   // one dependent chain per wave: as many waves as possible
+    if (d->schedule != LDPC_SCHED_FLOODING) return 1;      // layered: one dependent chain per wave, as many waves as possible
     return d->dtype == LDPC_F64 ? 2 : 4;
 }
 
@@ -350,12 +350,18 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     }
     HIP_TRY(hipGetLastError());
 
-    if (d->schedule == LDPC_SCHED_LAYERED_REF) {
+    if (d->schedule != LDPC_SCHED_FLOODING) {
         if constexpr (sizeof(T) == 4) {
-            // posteriors start as the LLRs and are updated in place, check after check, by one wave per tile
-            hipLaunchKernelGGL((layered_rcq<VEC>), dim3(w.tiles), dim3(kWave), 0, s, g, (float *)w.llrT, d->thresholds,
-                               d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters,
-                               d->g->max_dc);
+            // posteriors start as the LLRs and are updated in place, check after check, by one wave per tile;
+            // LDPC_SCHED_LAYERED keeps every edge's message code in the c2v buffer (subtracted before the check's update)
+            if (d->schedule == LDPC_SCHED_LAYERED)
+                hipLaunchKernelGGL((layered_rcq<VEC, true>), dim3(w.tiles), dim3(kWave), 0, s, g, (float *)w.llrT, d->thresholds,
+                                   d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters,
+                                   d->g->max_dc, (uint8_t *)w.c2v);
+            else
+                hipLaunchKernelGGL((layered_rcq<VEC, false>), dim3(w.tiles), dim3(kWave), 0, s, g, (float *)w.llrT, d->thresholds,
+                                   d->n_levels, (const int *)d->q_of_iter_dev, T_it, early_stop ? 1 : 0, w.bitsT, w.done, w.iters,
+                                   d->g->max_dc, (uint8_t *)nullptr);
             HIP_TRY(hipGetLastError());
             if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
             if (bits || posterior)
@@ -962,11 +968,12 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
     // association orders restated on the device: torch.sum below its cascade level, np.sum one block
     if (desc->dtype == LDPC_F32 && g->max_dv > 575) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 575 (fp32 sum order)", g->max_dv);
     if (desc->dtype == LDPC_F64 && g->max_dv > 128) return fail(LDPC_ERR_UNSUPPORTED, "variable degree %d > 128 (fp64 sum order)", g->max_dv);
-    if (desc->schedule != LDPC_SCHED_FLOODING && desc->schedule != LDPC_SCHED_LAYERED_REF) return fail(LDPC_ERR_ARG, "bad schedule");
-    if (desc->schedule == LDPC_SCHED_LAYERED_REF) {
+    if (desc->schedule < LDPC_SCHED_FLOODING || desc->schedule > LDPC_SCHED_LAYERED) return fail(LDPC_ERR_ARG, "bad schedule");
+    if (desc->schedule != LDPC_SCHED_FLOODING) {
         if (desc->c2v_form != LDPC_C2V_RCQ || desc->dtype != LDPC_F32)
             return fail(LDPC_ERR_UNSUPPORTED, "the layered schedule exists for the fp32 RCQ decoder only (rcq_decoder.py:281-350)");
-        if (g->m == 1) return fail(LDPC_ERR_UNSUPPORTED, "layered schedule on a single-check code");
+        if (g->m == 1 && desc->schedule == LDPC_SCHED_LAYERED_REF)
+            return fail(LDPC_ERR_UNSUPPORTED, "the reference's layered schedule on a single-check code");
     }
     if (desc->c2v_form == LDPC_C2V_RCQ) {
         if (desc->dtype != LDPC_F32) return fail(LDPC_ERR_UNSUPPORTED, "RCQ messages are fp32 only");

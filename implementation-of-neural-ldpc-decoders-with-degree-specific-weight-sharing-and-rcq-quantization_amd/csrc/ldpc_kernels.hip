@@ -1105,16 +1105,23 @@ __global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint6
 // parallelism is the batch.  Per check: pass 1 gathers the dc posterior rows (min1/min2/sign
 // parity), pass 2 re-reads each row, quantises-reconstructs sign*min and adds it in place.
 // ------------------------------------------------------------------------------------------
-template <int VEC>
+// PAPER = false: the schedule as the reference EXECUTES it (see above: the previous message is never subtracted).
+// PAPER = true : the layered schedule the reference's comments describe and the RCQ paper defines (LDPC_SCHED_LAYERED):
+//                the check's previous message (its 1-byte code, kept per edge in `codes`, reconstructed with the
+//                quantiser of the iteration that produced it) is subtracted from the posterior before the update,
+//                the new one is added and its code stored.  Nothing in the reference executes this: parity unpinned.
+template <int VEC, bool PAPER>
 __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restrict__ post,
                                                      const float *__restrict__ thresholds, int n_levels,
                                                      const int *__restrict__ q_of_iter, int T, int early_stop,
                                                      uint64_t *__restrict__ bitsT, uint64_t *__restrict__ done,
-                                                     int *__restrict__ iters, int max_dc)
+                                                     int *__restrict__ iters, int max_dc,
+                                                     uint8_t *__restrict__ codes)
 {
     constexpr int W = kWave * VEC;
     const int lane = threadIdx.x, tile = blockIdx.x;
     float *P = post + (size_t)tile * g.n * W + (size_t)lane * VEC;
+    uint8_t *Cd = PAPER ? codes + (size_t)tile * g.E * W + (size_t)lane * VEC : nullptr;
     unsigned frozen = 0;                                    // bit c: codeword c of this lane has stopped
 #pragma unroll
     for (int c = 0; c < VEC; ++c) frozen |= (unsigned)((done[(size_t)tile * VEC + c] >> lane) & 1ull) << c;
@@ -1134,10 +1141,18 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
         }
         return unsat;
     };
+    // value of a stored code under the quantiser that produced it: (1 - 2*sign) * tau[level]
+    auto rec_of = [&](const float *thr_q, unsigned code) {
+        const unsigned lvl = code >= (unsigned)n_levels ? code - (unsigned)n_levels : code;
+        float mag = thr_q[0];
+        for (int q = 1; q < n_levels; ++q) mag = (lvl == (unsigned)q) ? thr_q[q] : mag;
+        return flip_sign<float>(mag, code >= (unsigned)n_levels ? 1u : 0u);
+    };
 
     for (int it = 0; it < T; ++it) {
         if (early_stop && __ballot(frozen != kAll) == 0ull) break;
         const float *thr = thresholds + (size_t)q_of_iter[it] * n_levels;
+        const float *thr_prev = thresholds + (size_t)q_of_iter[it > 0 ? it - 1 : 0] * n_levels;
         if constexpr (VEC == 1) {
             // The walk is ONE dependent chain per wave (a check reads what the previous one wrote), so what counts is
             // memory round trips per check.  With at most kHeld edges per check: the indices of check i+1 are fetched
@@ -1146,25 +1161,34 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
             constexpr int kHeld = 32;
             if (max_dc <= kHeld) {
                 int var_n[kHeld];
-                int dc_n = 0;
+                int dc_n = 0, e0_n = 0;
                 auto fetch_idx = [&](int i) {
-                    const int e0n = g.check_ptr[i];
-                    dc_n = g.check_ptr[i + 1] - e0n;
+                    e0_n = g.check_ptr[i];
+                    dc_n = g.check_ptr[i + 1] - e0_n;
 #pragma unroll
                     for (int t = 0; t < kHeld; ++t)
-                        if (t < max_dc) var_n[t] = g.var_idx[min(e0n + t, g.E - 1)];      // past the check: unused
+                        if (t < max_dc) var_n[t] = g.var_idx[min(e0_n + t, g.E - 1)];      // past the check: unused
                 };
                 if (g.m > 0) fetch_idx(0);
                 for (int i = 0; i < g.m; ++i) {
                     int var[kHeld];
-                    const int dc = uni(dc_n);
+                    const int dc = uni(dc_n), e0 = uni(e0_n);
 #pragma unroll
                     for (int t = 0; t < kHeld; ++t) var[t] = var_n[t];
                     if (i + 1 < g.m) fetch_idx(i + 1);
                     float x[kHeld];
+                    unsigned old[kHeld];
 #pragma unroll
                     for (int t = 0; t < kHeld; ++t)
-                        if (t < dc) x[t] = P[(size_t)var[t] * W];
+                        if (t < dc) {
+                            x[t] = P[(size_t)var[t] * W];
+                            if (PAPER && it > 0) old[t] = Cd[(size_t)(e0 + t) * W];
+                        }
+                    if (PAPER && it > 0) {
+#pragma unroll
+                        for (int t = 0; t < kHeld; ++t)
+                            if (t < dc) x[t] = x[t] - rec_of(thr_prev, old[t]);          // "subtract previous C2V messages" (:300-302)
+                    }
                     float m1 = inf_of<float>(), m2 = inf_of<float>();
                     unsigned par = 0;
 #pragma unroll
@@ -1185,8 +1209,10 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
                                 const float w = flip_sign<float>(raw, par ^ signbit_of<float>(x[t]));
                                 const float mag = __builtin_fabsf(w);
                                 float rec = thr[0];
-                                for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                                unsigned lvl = 0;
+                                for (int q = 1; q < n_levels; ++q) { const bool ge = mag >= thr[q]; rec = ge ? thr[q] : rec; lvl = ge ? (unsigned)q : lvl; }
                                 P[(size_t)var[t] * W] = x[t] + flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
+                                if (PAPER) Cd[(size_t)(e0 + t) * W] = (uint8_t)(((w < 0.0f) ? (unsigned)n_levels : 0u) + lvl);
                             }
                     }
                 }
@@ -1201,9 +1227,19 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
             unsigned par[VEC];
 #pragma unroll
             for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); par[c] = 0; }
+            // PAPER: the posterior minus the check's previous message, recomputed identically in both passes
+            auto input = [&](int t) {
+                Pack<float, VEC> v = ld<float, VEC>(P + (size_t)g.var_idx[e0 + t] * W);
+                if (PAPER && it > 0) {
+                    const Pack<uint8_t, VEC> oc = ld<uint8_t, VEC>(Cd + (size_t)(e0 + t) * W);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) v.x[c] = v.x[c] - rec_of(thr_prev, oc.x[c]);
+                }
+                return v;
+            };
 #pragma unroll 4
             for (int t = 0; t < dc; ++t) {
-                const Pack<float, VEC> v = ld<float, VEC>(P + (size_t)g.var_idx[e0 + t] * W);
+                const Pack<float, VEC> v = input(t);
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
                     const float a = __builtin_fabsf(v.x[c]);
@@ -1219,7 +1255,8 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
 #pragma unroll 2
             for (int t = 0; t < dc; ++t) {
                 float *row = P + (size_t)g.var_idx[e0 + t] * W;
-                Pack<float, VEC> v = ld<float, VEC>(row);
+                Pack<float, VEC> v = input(t);
+                Pack<uint8_t, VEC> nc;
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) {
                     const float a = __builtin_fabsf(v.x[c]);
@@ -1227,11 +1264,29 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
                     const float w = flip_sign<float>(raw, par[c] ^ signbit_of<float>(v.x[c]));
                     const float mag = __builtin_fabsf(w);
                     float rec = thr[0];
-                    for (int q = 1; q < n_levels; ++q) rec = (mag >= thr[q]) ? thr[q] : rec;
+                    unsigned lvl = 0;
+                    for (int q = 1; q < n_levels; ++q) { const bool ge = mag >= thr[q]; rec = ge ? thr[q] : rec; lvl = ge ? (unsigned)q : lvl; }
                     const float msg = flip_sign<float>(rec, (w < 0.0f) ? 1u : 0u);
-                    if (!((frozen >> c) & 1u)) v.x[c] = v.x[c] + msg;
+                    nc.x[c] = (uint8_t)(((w < 0.0f) ? (unsigned)n_levels : 0u) + lvl);
+                    if ((frozen >> c) & 1u) {
+                        // a stopped codeword keeps posterior AND code: put back what `input` took off
+                        if (PAPER && it > 0) v.x[c] = ld<float, VEC>(row).x[c];
+                    } else {
+                        v.x[c] = v.x[c] + msg;
+                    }
                 }
-                if (frozen != kAll) st<float, VEC>(row, v);
+                if (frozen != kAll) {
+                    st<float, VEC>(row, v);
+                    if (PAPER) {
+                        if (frozen == 0) {
+                            st<uint8_t, VEC>(Cd + (size_t)(e0 + t) * W, nc);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < VEC; ++c)
+                                if (!((frozen >> c) & 1u)) Cd[(size_t)(e0 + t) * W + c] = nc.x[c];
+                        }
+                    }
+                }
             }
         }
     checks_done:

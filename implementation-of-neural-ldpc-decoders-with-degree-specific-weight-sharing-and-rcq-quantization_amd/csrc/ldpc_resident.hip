@@ -920,7 +920,7 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
                                                   dc_pre, b_pre, tid, nt);
         if (BPC && tid < pl.m && it + 1 < a.T)           // next iteration's beta: in flight across the phases below
             b_pre = g_beta[(size_t)(it + 1) * a.n_beta + pl.bslot_c[tid]];
-        __syncthreads();
+        if (!LDPC_PROBE(a, 128)) __syncthreads();   // probe 128: timing without the two barriers of an iteration (results are then wrong)
         if (ES && !a.posterior) {
             // reference stop rule without a second gather pass: the variable phase also yields this iteration's
             // hard decisions (the posterior shares the gathered C2V values); outputs are bits only
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
         if (it != a.T - 1 && !LDPC_PROBE(a, 2)) {
             if (a.unit_alpha) res_var_phase<G, 2, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
             else res_var_phase<G, 0, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
-            __syncthreads();
+            if (!LDPC_PROBE(a, 128)) __syncthreads();   // probe 128: timing without the two barriers of an iteration (results are then wrong)
         }
     }
 

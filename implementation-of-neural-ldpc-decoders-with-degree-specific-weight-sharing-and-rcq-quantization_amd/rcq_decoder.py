@@ -23,7 +23,11 @@ posteriors; because the reference re-creates its message matrix for every check,
 parity is the contract; a single-check code, the one case where the subtraction would be real,
 is rejected).
 
-Extensions: batched ``[B, n]`` input and ``early_stop=False`` as in the other decoders.
+Extensions: batched ``[B, n]`` input and ``early_stop=False`` as in the other decoders;
+``RCQMinSumDecoder(layered="paper")`` runs the layered schedule that code sets out to implement (previous message
+subtracted before a check's update, new one added -- the one change is the message matrix living across checks).
+Nothing in the reference executes it, so its parity is UNPINNED: it is checked against an independent CPU
+restatement only.
 """
 
 from __future__ import annotations
@@ -135,12 +139,13 @@ class RCQMinSumDecoder:
         g = self.code.tanner_graph()
         T = int(self.max_iterations)
         thr = _threshold_table(self.quantizers)
-        key = (dev.index, id(g), T, thr.tobytes(), bool(self.layered))
+        key = (dev.index, id(g), T, thr.tobytes(), self.layered if isinstance(self.layered, str) else bool(self.layered))
         if self._engine is None or self._engine_key != key:
             rows = max(T, 1)
             self._engine = DecodeEngine(
                 g, dtype=torch.float32, c2v_form=nat.C2V_RCQ, iters=T, device=dev,
-                schedule=nat.SCHED_LAYERED_REF if self.layered else nat.SCHED_FLOODING,
+                schedule=(nat.SCHED_LAYERED if self.layered == "paper" else
+                          nat.SCHED_LAYERED_REF if self.layered else nat.SCHED_FLOODING),
                 beta=np.ones((rows, 1), np.float32), beta_slot=np.zeros(g.E, np.int32),     # prod(signs) * min
                 alpha=np.ones((rows, 1), np.float32), alpha_slot=np.zeros(g.n, np.int32),   # llr + sum(others)
                 thresholds=thr, q_of_iter=_quantizer_schedule(len(self.quantizers), T))

@@ -60,8 +60,11 @@ enum {
 
 /* message schedule.  LAYERED_REF is RCQMinSumDecoder(layered=True) exactly as the reference runs it
  * (rcq_decoder.py:281-350): checks processed in order on running posteriors whose "previous
- * message" is never subtracted (the reference re-creates its message matrix per check); RCQ fp32 only. */
-enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED_REF = 1 };
+ * message" is never subtracted (the reference re-creates its message matrix per check); RCQ fp32 only.
+ * LAYERED is the schedule that code sets out to implement (and the RCQ paper defines): the check's previous
+ * message IS subtracted before its update and the new one added -- an extension with no reference execution
+ * to compare against (parity unpinned; checked against an independent CPU restatement only). */
+enum { LDPC_SCHED_FLOODING = 0, LDPC_SCHED_LAYERED_REF = 1, LDPC_SCHED_LAYERED = 2 };
 
 typedef struct ldpc_graph ldpc_graph;      /* Tanner graph, CSR + CSC, device resident */
 typedef struct ldpc_decoder ldpc_decoder;  /* graph + weight tables + quantiser LUTs    */
@@ -99,7 +102,7 @@ typedef struct {
     int32_t n_oms_alpha_slots;
     const void *oms_alpha;      /* [T][n_oms_alpha_slots] or NULL (= 0)                    */
     const int32_t *oms_alpha_slot; /* [E]                                                  */
-    int32_t schedule;           /* LDPC_SCHED_FLOODING (0) | LDPC_SCHED_LAYERED_REF                */
+    int32_t schedule;           /* LDPC_SCHED_FLOODING (0) | LDPC_SCHED_LAYERED_REF | LDPC_SCHED_LAYERED */
 } ldpc_decoder_desc;
 
 int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_decoder_desc *desc);

@@ -184,6 +184,83 @@ int oracle_decode_layered_f32(const oracle_graph *g, int T, const float *thresho
     return 0;
 }
 
+/* The layered schedule RCQMinSumDecoder._decode_layered sets out to implement (rcq_decoder.py:281-350 with ONE change: the
+ * message matrix c2v_messages is created once, before the loops, instead of inside the check loop at :323), i.e. the layered
+ * RCQ decoder of the paper: per check, subtract its previous (dequantised) messages from the posteriors, run the check
+ * update on them, store and add the new messages.  PARITY UNPINNED: nothing in the reference executes this. */
+static void layered_paper_one(const oracle_graph *g, int T, const float *thresholds, int n_levels, const int32_t *q_of_iter,
+                              const float *llr, int32_t *bits, float *post, int32_t *iters, uint8_t *success,
+                              float *sg, float *mg, float *c2v)
+{
+    const int n = g->n, m = g->m;
+    for (int j = 0; j < n; ++j) post[j] = llr[j];
+    for (int e = 0; e < g->check_ptr[m]; ++e) c2v[e] = 0.0f;
+    for (int it = 0; it < T; ++it) {
+        const float *thr = thresholds + (size_t)q_of_iter[it] * n_levels;
+        for (int i = 0; i < m; ++i) {
+            const int e0 = g->check_ptr[i], dc = g->check_ptr[i + 1] - e0;
+            if (dc == 0) continue;
+            for (int t = 0; t < dc; ++t) post[g->var_idx[e0 + t]] -= c2v[e0 + t];          /* :300-302 */
+            for (int t = 0; t < dc; ++t) {
+                float in = post[g->var_idx[e0 + t]];
+                sg[t] = in > 0 ? 1.0f : (in < 0 ? -1.0f : 0.0f);
+                mg[t] = fabsf(in);
+            }
+            int k = 0;
+            for (int t = 1; t < dc; ++t) if (mg[t] < mg[k]) k = t;
+            float m1 = mg[k], m2 = m1;
+            if (dc > 1) {
+                m2 = INFINITY;
+                for (int t = 0; t < dc; ++t) if (t != k && mg[t] < m2) m2 = mg[t];
+            }
+            for (int t = 0; t < dc; ++t) {
+                float prod = 1.0f;
+                for (int u = 0; u < dc; ++u) if (u != t) prod = prod * sg[u];
+                float w = prod * ((t == k) ? m2 : m1);
+                float mag = fabsf(w);
+                int lvl = 0;
+                for (int q = 0; q < n_levels; ++q) if (mag >= thr[q]) lvl = q;
+                int sb = w < 0.0f;
+                c2v[e0 + t] = (1.0f - 2.0f * (float)sb) * thr[lvl];
+            }
+            for (int t = 0; t < dc; ++t) post[g->var_idx[e0 + t]] += c2v[e0 + t];          /* :338-339 */
+        }
+        int unsat = 0;
+        for (int j = 0; j < n; ++j) bits[j] = post[j] < 0 ? 1 : 0;
+        for (int i = 0; i < m; ++i) {
+            int par = 0;
+            for (int e = g->check_ptr[i]; e < g->check_ptr[i + 1]; ++e) par ^= bits[g->var_idx[e]];
+            unsat += par;
+        }
+        if (unsat == 0) { *iters = it + 1; *success = 1; return; }
+    }
+    for (int j = 0; j < n; ++j) bits[j] = post[j] < 0 ? 1 : 0;
+    *iters = T; *success = 0;
+}
+
+int oracle_decode_layered_paper_f32(const oracle_graph *g, int T, const float *thresholds, int n_levels,
+                                    const int32_t *q_of_iter, const float *llr, int B,
+                                    int32_t *bits, float *post, int32_t *iters, uint8_t *success)
+{
+    int max_dc = 1;
+    const int E = g->check_ptr[g->m];
+    for (int i = 0; i < g->m; ++i) { int d = g->check_ptr[i + 1] - g->check_ptr[i]; if (d > max_dc) max_dc = d; }
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        float *tmp = (float *)malloc(sizeof(float) * ((size_t)max_dc * 2 + (size_t)(E > 0 ? E : 1)));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < B; ++b)
+            layered_paper_one(g, T, thresholds, n_levels, q_of_iter, llr + (size_t)b * g->n, bits + (size_t)b * g->n,
+                              post + (size_t)b * g->n, iters + b, success + b, tmp, tmp + max_dc, tmp + 2 * max_dc);
+        free(tmp);
+    }
+    return 0;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

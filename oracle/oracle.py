@@ -75,6 +75,9 @@ def lib():
         _lib.oracle_quantize_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib.oracle_dequantize_f32.restype = None
         _lib.oracle_dequantize_f32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.oracle_decode_layered_paper_f32.restype = C.c_int
+        _lib.oracle_decode_layered_paper_f32.argtypes = [C.POINTER(_Graph), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.oracle_decode_layered_f32.restype = C.c_int
         _lib.oracle_decode_layered_f32.argtypes = [C.POINTER(_Graph), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -309,8 +312,9 @@ def neural_minsum(g: OracleGraph, llr, T: int, beta: Dict[str, float], offset: b
                   alpha=np.ones((max(T, 1), 1), np.float32), alpha_slot=np.zeros(g.n, np.int32), **kw)
 
 
-def rcq_layered(g: OracleGraph, llr, bc: int, quantizer_params, T: int):
-    """RCQMinSumDecoder(layered=True).decode (rcq_decoder.py:281-350), bug-compatible.
+def rcq_layered(g: OracleGraph, llr, bc: int, quantizer_params, T: int, paper: bool = False):
+    """RCQMinSumDecoder(layered=True).decode (rcq_decoder.py:281-350), bug-compatible; paper=True: the schedule that
+    code sets out to implement (message matrix kept across checks) -- PARITY UNPINNED, nothing in the reference runs it.
     Returns (bits, final posteriors, iterations, success)."""
     thr = np.ascontiguousarray([quantizer_thresholds(bc, c, gm) for c, gm in quantizer_params], dtype=np.float32)
     sched = quantizer_schedule(T, len(quantizer_params))
@@ -318,8 +322,8 @@ def rcq_layered(g: OracleGraph, llr, bc: int, quantizer_params, T: int):
     B = x.shape[0]
     bits = np.zeros((B, g.n), np.int32); post = np.zeros((B, g.n), np.float32)
     iters = np.zeros(B, np.int32); succ = np.zeros(B, np.uint8)
-    rc = lib().oracle_decode_layered_f32(C.byref(g._c), T, _p(thr), thr.shape[1], _p(sched), _p(x), B,
-                                         _p(bits), _p(post), _p(iters), _p(succ))
+    fn = lib().oracle_decode_layered_paper_f32 if paper else lib().oracle_decode_layered_f32
+    rc = fn(C.byref(g._c), T, _p(thr), thr.shape[1], _p(sched), _p(x), B, _p(bits), _p(post), _p(iters), _p(succ))
     if rc != 0:
         raise RuntimeError("oracle_decode_layered failed")
     return bits, post, iters, succ.astype(bool)
