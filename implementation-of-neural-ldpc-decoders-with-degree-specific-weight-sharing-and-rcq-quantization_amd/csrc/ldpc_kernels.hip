@@ -864,7 +864,7 @@ __global__ __launch_bounds__(kBlock, LDPC_GATHER_WAVES) void cn_gather(GraphDev 
                                                     const float *__restrict__ alpha_prev_row,
                                                     const float *__restrict__ thr, int n_levels,
                                                     const float *__restrict__ lut_prev, int lut_entries,
-                                                    const uint64_t *__restrict__ done, int check_blocks)
+                                                    const uint64_t *__restrict__ done, int check_blocks, int xcd_tiles)
 {
     constexpr int W = kWave * VEC;
     // reconstruction values of the PREVIOUS iteration's quantiser (the one that produced codes_in), at LDS offset 0.
@@ -874,8 +874,21 @@ __global__ __launch_bounds__(kBlock, LDPC_GATHER_WAVES) void cn_gather(GraphDev 
     for (int k = threadIdx.x; k < lut_entries; k += kBlock) gather_lut_s[k] = lut_prev[k];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1);
-    const int tile = uni(blockIdx.x / check_blocks);
-    const int ibase = uni(((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
+    // xcd_tiles > 0: XCD-affine mapping -- workgroups are dealt round-robin to the 8 XCDs, so workgroup b works on tile
+    // 8*(b/8/check_blocks) + b%8: every tile is processed by ONE XCD and the re-reads of its rows (each LLR row dv times, each
+    // code row dv-1 times) meet in that XCD's L2 instead of in eight
+    int tile_, cblk_;
+    if (xcd_tiles > 0) {
+        const int k = blockIdx.x >> 3;
+        tile_ = (k / check_blocks) * 8 + (blockIdx.x & 7);
+        cblk_ = k % check_blocks;
+        if (tile_ >= xcd_tiles) return;
+    } else {
+        tile_ = blockIdx.x / check_blocks;
+        cblk_ = blockIdx.x % check_blocks;
+    }
+    const int tile = uni(tile_);
+    const int ibase = uni((cblk_ * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
     if (ibase >= g.m) return;
 
     Frozen<VEC> fz;

@@ -863,14 +863,19 @@ def test_fp64_basic_runs_on_the_resident_engine_with_identical_results(gpu_devic
 
 def _random_code(rng, T):
     """random sparse graph the resident engine accepts: check degrees 1..20, variable degrees <= 8, now and then a
-    degree-0 check or variable"""
+    degree-0 check or variable -- and in a third of the graphs a few WIDE checks (33..150 edges: lane-group split in the
+    resident engine, wave split in the streaming engine)"""
     from ldpc_decoder import LDPCCode
     m = int(rng.integers(4, 60))
     n = int(rng.integers(m + 3, 160))
     H = np.zeros((m, n), dtype=np.int64)
     room = np.full(n, 8)
+    wide = set(rng.choice(m, size=int(rng.integers(1, 4)), replace=False).tolist()) if (n > 40 and rng.random() < 0.33) else set()
     for i in range(m):
-        dc = int(rng.integers(0 if rng.random() < 0.05 else 1, min(20, n) + 1))
+        if i in wide:
+            dc = int(rng.integers(33, min(150, n) + 1))
+        else:
+            dc = int(rng.integers(0 if rng.random() < 0.05 else 1, min(20, n) + 1))
         cand = np.flatnonzero(room > 0)
         pick = rng.choice(cand, size=min(dc, len(cand)), replace=False)
         H[i, pick] = 1
@@ -878,7 +883,11 @@ def _random_code(rng, T):
     return LDPCCode(n=n, k=max(n - m, 1), H=H, max_iterations=T)
 
 
-@pytest.mark.parametrize("seed", range(10))
+import os as _os
+_FUZZ_SEEDS = int(_os.environ.get("LDPC_FUZZ_SEEDS", "12"))     # tools/fuzz_round.sh runs the same property over hundreds of seeds
+
+
+@pytest.mark.parametrize("seed", range(_FUZZ_SEEDS))
 def test_random_graphs_engines_agree_with_the_oracle(seed, gpu_device, oracle_mod):
     """property test over random Tanner graphs: for every decoder form the resident engine, the streaming engine and the
     CPU oracle give the same bits / iterations / success (and the two engines bit-identical posteriors)"""
@@ -902,10 +911,11 @@ def test_random_graphs_engines_agree_with_the_oracle(seed, gpu_device, oracle_mo
         eng.set_mode("auto")
         assert eng.info()["engine"] == "resident"
         a = eng.decode(inp, early_stop=early, want_packed=True)
-        eng.set_mode("stream")
-        b = eng.decode(inp, early_stop=early, want_packed=True)
-        assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
-        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)
+        for mode in ("stream", "sweeps"):
+            eng.set_mode(mode)
+            b = eng.decode(inp, early_stop=early, want_packed=True)
+            assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
+            assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)
         return a
 
     wtype = int(rng.integers(1, 5))
