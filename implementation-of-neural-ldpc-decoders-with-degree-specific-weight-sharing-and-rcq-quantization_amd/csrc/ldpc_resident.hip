@@ -79,6 +79,9 @@ constexpr int kResHeld = 16;         // check degrees up to this keep their valu
                                      // (measured on one box, (1998,1512) Basic / RCQ: 0: 3.10 / 3.30 ms, 1: 3.13 / 3.33, 2: 3.20 / 3.48;
                                      //  LDPC_RES_VAR_MODE 1 costs another 0.15-0.25 ms: DESIGN.md 5)
 #endif
+#ifndef LDPC_RES_NO_PLAN_PREFETCH
+#define LDPC_RES_NO_PLAN_PREFETCH 0
+#endif
 #ifndef LDPC_RES_VAR_MODE
 #define LDPC_RES_VAR_MODE 0          // 0 per-lane dispatch | 1 one scalar pass per distinct degree
 #endif
@@ -620,11 +623,13 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
         const int qn = q + nt;
         unsigned metan = 0;
         uint4 slon = zero4, shin = zero4;
+#if !LDPC_RES_NO_PLAN_PREFETCH                        // tuning builds with more waves per SIMD trade the prefetch for registers
         if (qn < n) {
             metan = pl.vmeta[qn];
             slon = pl.vslot_lo[qn];
             if (wide) shin = pl.vslot_hi[qn];
         }
+#endif
         const int dv = (int)(meta & 0xffu);
         T a = (T)0;                                                      // LDS copy of the table when small
         if (MODE == 0 || MODE == 4) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
@@ -642,6 +647,13 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
 #else
         // every lane jumps to the compile-time body of ITS degree (exec-masked dispatch): one pass per wave whatever the mix
         res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask);
+#endif
+#if LDPC_RES_NO_PLAN_PREFETCH
+        if (qn < n) {
+            metan = pl.vmeta[qn];
+            slon = pl.vslot_lo[qn];
+            if (wide) shin = pl.vslot_hi[qn];
+        }
 #endif
         q = qn; meta = metan; slo = slon; shi = shin;
     }
