@@ -538,11 +538,12 @@ int resident_alpha_floats(const ldpc_decoder *d)
 }
 
 // G codewords per workgroup fit when the state is within LDS and slot byte offsets fit 16 bits
-bool resident_fits(const ldpc_decoder *d, long long S, int G, int blocks)
+bool resident_fits(const ldpc_decoder *d, long long S, int G, int blocks, int m_par)
 {
     if (S * G * 4 > 65535) return false;
-    return blocks * res_lds_total((int)S, d->g->n, G, resident_alpha_floats(d)) <= kLdsBytes;
+    return blocks * res_lds_total((int)S, d->g->n, G, resident_alpha_floats(d), m_par) <= kLdsBytes;
 }
+bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 // ---- LDS bank-conflict-aware lane assignment -------------------------------------------------
 // The check phase touches consecutive slots (conflict-free by construction); the variable phase
@@ -669,15 +670,16 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     // LDPC_RESIDENT_G / _NT override for tuning (read only by -DLDPC_RESIDENT_PROBES builds).
     auto geometry = [&](int stride, int &G_out, int &blocks_out) {
         const long long S_ = (long long)max_sub * stride;
-        if (S_ > 65535 || !resident_fits(d, S_, 1, 1)) return false;
+        const int mp = is_pow2(stride) ? m : 0;           // parity words of the early-stop syndrome (power-of-two strides)
+        if (S_ > 65535 || !resident_fits(d, S_, 1, 1, mp)) return false;
         int G_ = 0;
 #ifdef LDPC_RESIDENT_PROBES
         const char *eg = getenv("LDPC_RESIDENT_G");
         if (eg) G_ = atoi(eg);
 #endif
-        if (!((G_ == 1 || G_ == 2) && resident_fits(d, S_, G_, 1))) G_ = resident_fits(d, S_, 2, 1) ? 2 : 1;
+        if (!((G_ == 1 || G_ == 2) && resident_fits(d, S_, G_, 1, mp))) G_ = resident_fits(d, S_, 2, 1, mp) ? 2 : 1;
         int b_ = 1;
-        while (b_ < 8 && resident_fits(d, S_, G_, b_ + 1)) ++b_;
+        while (b_ < 8 && resident_fits(d, S_, G_, b_ + 1, mp)) ++b_;
         G_out = G_; blocks_out = b_;
         return true;
     };
@@ -744,6 +746,8 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     pl = ResidentPlan{};
     pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = max_sub; pl.max_dv = g->max_dv; pl.mstride = mstride; pl.E = g->E;
     pl.any_split = any_split ? 1 : 0;
+    pl.par_words = is_pow2(mstride) ? m : 0;
+    pl.par_shift = G == 2 ? 3 : 2;                     // slot byte offset = slot * G * 4
     int rc = plan_upload(d, &pl.dc_s, dc_s);
     if (!rc && any_split) rc = plan_upload(d, &pl.gsz, gsz);
     if (!rc) rc = plan_upload(d, &pl.cvar, cvar);
@@ -757,7 +761,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     if (!rc) rc = plan_upload(d, &pl.edge_of_slot, edge_of_slot);
     if (rc) return rc;
     d->res_G = G; d->res_NT = NT;
-    d->res_lds = res_lds_total((int)S, n, G, resident_alpha_floats(d));
+    d->res_lds = res_lds_total((int)S, n, G, resident_alpha_floats(d), pl.par_words);
     d->res_ok = true;
     return LDPC_OK;
 }

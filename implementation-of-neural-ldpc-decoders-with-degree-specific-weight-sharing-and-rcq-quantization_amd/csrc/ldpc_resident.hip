@@ -41,6 +41,8 @@ struct ResidentPlan {
     const uint8_t *gsz;           // [m] or null  lane-group size of position p: a check wider than the slot layout admits is
                                   //              split over 2^k ADJACENT lanes (sub-checks of contiguous edges); 1 = whole check
     int any_split;                // some check is split (gsz != null): the host launches the SPLIT instantiation of the kernel
+    int par_words;                // m when the row stride is a power of two: parity words of the early-stop syndrome (ParScatter)
+    int par_shift;                // log2 of the bytes per slot
     const uint16_t *cvar;         // [max_dc*m]   sorted position of the variable of edge (p,t)
     const uint16_t *bslot;        // [max_dc*m]   beta table column of edge (p,t)
     const uint16_t *bslot_c;      // [m] or null: column shared by all edges of check p (Basic, RCQ,
@@ -117,6 +119,20 @@ __device__ __forceinline__ void lds_store(unsigned byte_off, const X &v)
     u.k = v;
     *(LP)(size_t)byte_off = u.v;
 }
+
+__device__ __forceinline__ void lds_atomic_xor(unsigned byte_off, unsigned v)
+{
+    using LP = __attribute__((address_space(3))) unsigned *;
+    __hip_atomic_fetch_xor((LP)(size_t)byte_off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Early-stop syndrome without a second gather: the variable lane that has just formed a hard decision XORs it into the
+// parity word of each of its checks (one LDS atomic per edge).  The check position is recovered from the edge's slot
+// offset -- slot(p,t) = t*stride + p with a power-of-two stride: p = (offset >> shift) & mask -- so no index data is
+// loaded; `par_off` = 0 switches the scatter off (then the checks gather the decisions, res_syndrome_phase).
+struct ParScatter {
+    unsigned par_off = 0, shift = 0, mask = 0;
+};
 
 __device__ __forceinline__ bool wave_uniform(int v, int &vw)
 {
@@ -528,7 +544,7 @@ __device__ __forceinline__ void res_check_phase(const ResidentPlan &pl, unsigned
 template <int G, int DV, int MODE, typename T>
 __device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict__ llr_s,
                                              uint8_t *__restrict__ bits_s, int q, const uint4 &slo, const uint4 &shi,
-                                             T a, unsigned emask)
+                                             T a, unsigned emask, const ParScatter &ps)
 {
     using P = Pack<T, G>;
     constexpr int ORD = std::is_same<T, float>::value ? 0 : 1;       // torch.sum fp32 order / np.sum fp64 order
@@ -559,7 +575,13 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict_
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) lds_store<P>(off[k], out[k]);
-        if constexpr ((MODE & 4) != 0) bits_s[q] = (uint8_t)byte;
+        if constexpr ((MODE & 4) != 0) {
+            bits_s[q] = (uint8_t)byte;
+            if (ps.par_off) {
+#pragma unroll
+                for (int k = 0; k < DV; ++k) lds_atomic_xor(ps.par_off + (((off[k] >> ps.shift) & ps.mask) << 2), byte);
+            }
+        }
     } else {
         unsigned byte = 0;
         bool store = false;
@@ -580,6 +602,10 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict_
             for (int k = 0; k < DV; ++k) lds_store<unsigned>(off[k], byte);
         } else {
             bits_s[q] = (uint8_t)byte;
+            if (ps.par_off) {
+#pragma unroll
+                for (int k = 0; k < DV; ++k) lds_atomic_xor(ps.par_off + (((off[k] >> ps.shift) & ps.mask) << 2), byte);
+            }
         }
         if (store) L[q] = l;
     }
@@ -588,9 +614,9 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict_
 template <int G, int MODE, typename T>
 __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, T *__restrict__ llr_s,
                                                  uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &slo,
-                                                 const uint4 &shi, T a, unsigned emask)
+                                                 const uint4 &shi, T a, unsigned emask, const ParScatter &ps)
 {
-#define LDPC_RV(D) case D: res_var_body<G, D, MODE, T>(smem, llr_s, bits_s, q, slo, shi, a, emask); break;
+#define LDPC_RV(D) case D: res_var_body<G, D, MODE, T>(smem, llr_s, bits_s, q, slo, shi, a, emask, ps); break;
     switch (dv) {
         LDPC_RV(0) LDPC_RV(1) LDPC_RV(2) LDPC_RV(3) LDPC_RV(4) LDPC_RV(5) LDPC_RV(6) LDPC_RV(7) LDPC_RV(8)
     default: break;   // host admits only max_dv <= 8 to this engine
@@ -606,7 +632,7 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
                                               T *__restrict__ llr_s, uint8_t *__restrict__ bits_s,
                                               const T *__restrict__ alpha_lds,
                                               const T *__restrict__ alpha_glb, unsigned emask,
-                                              int tid, int nt)
+                                              int tid, int nt, const ParScatter ps = ParScatter{})
 {
     const int n = pl.n;
     const bool wide = pl.max_dv > 4;
@@ -641,12 +667,12 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
             int dsel = dvw;
             asm volatile("" : "+s"(dsel));
             const bool mine = dv == dvw;
-            if (mine) res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dsel, slo, shi, a, emask);
+            if (mine) res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dsel, slo, shi, a, emask, ps);
             todo &= ~__ballot(mine);
         }
 #else
         // every lane jumps to the compile-time body of ITS degree (exec-masked dispatch): one pass per wave whatever the mix
-        res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask);
+        res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask, ps);
 #endif
 #if LDPC_RES_NO_PLAN_PREFETCH
         if (qn < n) {
@@ -676,6 +702,21 @@ __device__ __forceinline__ void res_syndrome_phase(const ResidentPlan &pl, const
             for (int t = 0; t < dc; ++t) x ^= bits_s[pl.cvar[t * pl.mstride + p]];
         }
         if constexpr (SPLIT) x = group_xor(pl.gsz[p], x);   // a split check's parity is the XOR over its lane group
+        acc |= x;
+    }
+    if (acc) atomicOr(sh_unsat, acc);
+}
+
+// syndrome from the parity words the variable lanes scattered into (ParScatter): OR of all checks' parities -> *sh_unsat,
+// and the words are cleared for the next iteration
+template <int G, bool SPLIT>
+__device__ __forceinline__ void res_parity_reduce(const ResidentPlan &pl, unsigned par_off, unsigned *sh_unsat, int tid, int nt)
+{
+    unsigned acc = 0;
+    for (int p = tid; p < pl.m; p += nt) {
+        unsigned x = lds_load<unsigned>(par_off + 4u * (unsigned)p);
+        lds_store<unsigned>(par_off + 4u * (unsigned)p, 0u);
+        if constexpr (SPLIT) x = group_xor(pl.gsz[p], x);
         acc |= x;
     }
     if (acc) atomicOr(sh_unsat, acc);
@@ -817,7 +858,9 @@ __host__ __device__ inline size_t res_off_llr(int S, int G) { return (size_t)S *
 __host__ __device__ inline size_t res_off_alpha(int S, int n, int G) { return res_off_llr(S, G) + (size_t)n * G * 4; }
 __host__ __device__ inline size_t res_off_bits(int S, int n, int G, int n_alpha_lds) { return res_off_alpha(S, n, G) + (size_t)n_alpha_lds * 4; }
 __host__ __device__ inline size_t res_off_flag(int S, int n, int G, int n_alpha_lds) { return (res_off_bits(S, n, G, n_alpha_lds) + n + 3) / 4 * 4; }
-__host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
+__host__ __device__ inline size_t res_off_par(int S, int n, int G, int n_alpha_lds) { return res_off_flag(S, n, G, n_alpha_lds) + 16; }
+// `m_par` parity words follow (early-stop syndrome by scatter); 0 when the stride is not a power of two
+__host__ __device__ inline size_t res_lds_total(int S, int n, int G, int n_alpha_lds, int m_par) { return res_off_par(S, n, G, n_alpha_lds) + 4 * (size_t)m_par; }
 
 // ES: 0 = fixed-iteration kernel, 1 = early-stop kernel (kept apart so that the fixed-T kernel does not carry
 // the posterior/syndrome/emit code of the stop rule: the extra code cost the hot loop ~4 % when merged)
@@ -839,6 +882,12 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
     T *alpha_s = reinterpret_cast<T *>(res_smem + res_off_alpha(pl.S, pl.n, GE));
     uint8_t *bits_s = res_smem + res_off_bits(pl.S, pl.n, GE, n_alpha_lds);
     unsigned *sh_unsat = reinterpret_cast<unsigned *>(res_smem + res_off_flag(pl.S, pl.n, GE, n_alpha_lds));
+    ParScatter ps;
+    if (ES && pl.par_words) {
+        ps.par_off = (unsigned)res_off_par(pl.S, pl.n, GE, n_alpha_lds);
+        ps.shift = (unsigned)pl.par_shift;
+        ps.mask = (unsigned)pl.mstride - 1u;
+    }
     const T *g_llr = reinterpret_cast<const T *>(a.llr);
     const T *g_beta = reinterpret_cast<const T *>(a.beta);
     const T *g_alpha = reinterpret_cast<const T *>(a.alpha);
@@ -874,7 +923,9 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
         }
     }
     for (int k = tid; k < (a.alpha_in_lds ? a.T * a.n_alpha : 0); k += nt) alpha_s[k] = g_alpha[k];
-    if (tid == 0) *sh_unsat = 0;
+    if (tid == 0) { sh_unsat[0] = 0; sh_unsat[1] = 0; }
+    if (ES)
+        for (int k = tid; k < pl.par_words; k += nt) lds_store<unsigned>(ps.par_off + 4u * (unsigned)k, 0u);
     __syncthreads();
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
@@ -937,15 +988,18 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
             // reference stop rule without a second gather pass: the variable phase also yields this iteration's
             // hard decisions (the posterior shares the gathered C2V values); outputs are bits only
             const bool last = it == a.T - 1;
-            if (last) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
-            else if (a.unit_alpha) res_var_phase<G, 6, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
-            else res_var_phase<G, 4, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt);
+            if (last) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt, ps);
+            else if (a.unit_alpha) res_var_phase<G, 6, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt, ps);
+            else res_var_phase<G, 4, T>(pl, res_smem, llr_s, bits_s, alpha_lds, alpha_glb, 0u, tid, nt, ps);
             __syncthreads();
-            res_syndrome_phase<G, SPLIT>(pl, bits_s, sh_unsat, tid, nt);
+            // the flag word alternates between iterations: this one's is read after ONE barrier while thread 0 already clears
+            // the other one for the next iteration (no third barrier)
+            unsigned *su = sh_unsat + (it & 1);
+            if (ps.par_off) res_parity_reduce<G, SPLIT>(pl, ps.par_off, su, tid, nt);    // the variable lanes scattered the parities
+            else res_syndrome_phase<G, SPLIT>(pl, bits_s, su, tid, nt);
             __syncthreads();
-            const unsigned unsat = *sh_unsat;
-            __syncthreads();
-            if (tid == 0) *sh_unsat = 0;
+            const unsigned unsat = *su;
+            if (tid == 0) sh_unsat[(it + 1) & 1] = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
                 res_emit_bits<G>(pl, a, bits_s, b0, newly, it + 1, 0u, tid, nt);
@@ -956,13 +1010,14 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
             continue;
         }
         if (ES) {
-            res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt);
+            res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, 0u, tid, nt, ps);
             __syncthreads();
-            res_syndrome_phase<G, SPLIT>(pl, bits_s, sh_unsat, tid, nt);
+            unsigned *su = sh_unsat + (it & 1);
+            if (ps.par_off) res_parity_reduce<G, SPLIT>(pl, ps.par_off, su, tid, nt);
+            else res_syndrome_phase<G, SPLIT>(pl, bits_s, su, tid, nt);
             __syncthreads();
-            const unsigned unsat = *sh_unsat;
-            __syncthreads();
-            if (tid == 0) *sh_unsat = 0;
+            const unsigned unsat = *su;
+            if (tid == 0) sh_unsat[(it + 1) & 1] = 0;
             const unsigned newly = ~unsat & ~done & kAll;
             if (newly) {                                 // block-uniform
                 if (a.dbg_c2v) res_dump_c2v<G, T>(pl, a, b0, newly, tid, nt);      // slots still hold this iteration's C2V
