@@ -715,7 +715,8 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     std::vector<uint8_t> dc_s(m), gsz(m);
     std::vector<uint16_t> cvar((size_t)S, 0), bslot((size_t)S, 0), oaslot((size_t)S, 0), bslot_c(m, 0), inv(n);
     std::vector<uint32_t> vmeta(n);
-    std::vector<uint4> vslot_lo(n), vslot_hi(n);
+    std::vector<uint2> vslot_lo(n), vslot_hi(std::max(n, 1));
+    int n_hi = 0;
     std::vector<uint32_t> edge_of_slot((size_t)S, 0xffffffffu);
     bool per_check = true;
     for (int p = 0; p < m; ++p) {
@@ -739,13 +740,15 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
         inv[j] = (uint16_t)q;
         uint32_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < dv; ++k) off[k] = (uint32_t)slot_of_edge[g->h_csc[s0 + k]] * G * 4;
-        vslot_lo[q] = make_uint4(off[0], off[1], off[2], off[3]);
-        vslot_hi[q] = make_uint4(off[4], off[5], off[6], off[7]);
+        vslot_lo[q] = make_uint2(off[0] | (off[1] << 16), off[2] | (off[3] << 16));      // offsets <= 65535 (resident_fits)
+        vslot_hi[q] = make_uint2(off[4] | (off[5] << 16), off[6] | (off[7] << 16));
+        if (dv > 4) n_hi = q + 1;                                                     // degree-sorted: they come first
     }
     ResidentPlan &pl = d->res;
     pl = ResidentPlan{};
     pl.n = n; pl.m = m; pl.S = (int)S; pl.max_dc = max_sub; pl.max_dv = g->max_dv; pl.mstride = mstride; pl.E = g->E;
     pl.any_split = any_split ? 1 : 0;
+    pl.n_hi = n_hi;
     pl.par_words = is_pow2(mstride) ? m : 0;
     pl.par_shift = G == 2 ? 3 : 2;                     // slot byte offset = slot * G * 4
     int rc = plan_upload(d, &pl.dc_s, dc_s);
@@ -756,6 +759,7 @@ int build_resident_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     if (!rc && d->form == LDPC_C2V_OMS && desc->oms_alpha) rc = plan_upload(d, &pl.oaslot, oaslot);
     if (!rc) rc = plan_upload(d, &pl.vmeta, vmeta);
     if (!rc) rc = plan_upload(d, &pl.vslot_lo, vslot_lo);
+    vslot_hi.resize((size_t)std::max(n_hi, 1));
     if (!rc) rc = plan_upload(d, &pl.vslot_hi, vslot_hi);
     if (!rc) rc = plan_upload(d, &pl.inv_perm_v, inv);
     if (!rc) rc = plan_upload(d, &pl.edge_of_slot, edge_of_slot);

@@ -49,8 +49,13 @@ struct ResidentPlan {
                                   //              sharing types 2-4) -> one table read per check
     const uint16_t *oaslot;       // [max_dc*m]   OMS alpha column (or null)
     const uint32_t *vmeta;        // [n]          degree | alpha column << 8 of sorted variable q
-    const uint4 *vslot_lo;        // [n]          LDS byte offsets (= slot * G * 4) of edges k = 0..3 of q
-    const uint4 *vslot_hi;        // [n]          ... of edges k = 4..7 (read only when max_dv > 4)
+    const uint2 *vslot_lo;        // [n]          LDS byte offsets (= slot * G * 4, all <= 65535) of edges k = 0..3 of q, four
+                                  //              16-bit values in 8 bytes
+    const uint2 *vslot_hi;        // [n_hi]       ... of edges k = 4..7, for the n_hi leading (highest-degree) variables only
+    int n_hi;                     //              variables of degree > 4 (they come first in the degree-sorted order)
+                                  // 8 + 8 + 4 bytes per variable: the whole plan of the (1998,1512) code is 26 KB and stays in
+                                  // the CU's 32 KiB L1 across iterations (with 32-bit offsets and the hi half read for every
+                                  // variable it was 72 KB per workgroup and iteration from L2)
     const uint16_t *inv_perm_v;   // [n]          sorted position of original variable j
     int E;                        // edges of the graph
     const uint32_t *edge_of_slot; // [S]          CSR edge id held by a slot, 0xffffffff for padding slots (test hook
@@ -80,6 +85,9 @@ constexpr int kResHeld = 16;         // check degrees up to this keep their valu
 #define LDPC_RES_CHECK_MODE 0        // 0 per-lane form only | 1 scalar form for single-degree waves | 2 one scalar pass per degree
                                      // (measured on one box, (1998,1512) Basic / RCQ: 0: 3.10 / 3.30 ms, 1: 3.13 / 3.33, 2: 3.20 / 3.48;
                                      //  LDPC_RES_VAR_MODE 1 costs another 0.15-0.25 ms: DESIGN.md 5)
+#endif
+#ifndef LDPC_RES_FINAL_SCATTER
+#define LDPC_RES_FINAL_SCATTER 1      // fixed T: final syndrome by parity scatter (0: decisions through the dead message slots)
 #endif
 #ifndef LDPC_RES_NO_PLAN_PREFETCH
 #define LDPC_RES_NO_PLAN_PREFETCH 0
@@ -611,6 +619,11 @@ __device__ __forceinline__ void res_var_body(unsigned char *smem, T *__restrict_
     }
 }
 
+__device__ __forceinline__ uint4 plan_unpack(const uint2 &p)
+{
+    return make_uint4(p.x & 0xffffu, p.x >> 16, p.y & 0xffffu, p.y >> 16);
+}
+
 template <int G, int MODE, typename T>
 __device__ __forceinline__ void res_var_dispatch(unsigned char *smem, T *__restrict__ llr_s,
                                                  uint8_t *__restrict__ bits_s, int q, int dv, const uint4 &slo,
@@ -634,29 +647,29 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
                                               const T *__restrict__ alpha_glb, unsigned emask,
                                               int tid, int nt, const ParScatter ps = ParScatter{})
 {
-    const int n = pl.n;
-    const bool wide = pl.max_dv > 4;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int n = pl.n, n_hi = pl.n_hi;
+    const uint2 zero2 = make_uint2(0, 0);
     int q = tid;
     unsigned meta = 0;
-    uint4 slo = zero4, shi = zero4;
+    uint2 plo = zero2, phi = zero2;                      // packed offsets, unpacked at the point of use
     if (q < n) {
         meta = pl.vmeta[q];
-        slo = pl.vslot_lo[q];
-        if (wide) shi = pl.vslot_hi[q];
+        plo = pl.vslot_lo[q];
+        if (q < n_hi) phi = pl.vslot_hi[q];
     }
     while (q < n) {
         const int qn = q + nt;
         unsigned metan = 0;
-        uint4 slon = zero4, shin = zero4;
+        uint2 plon = zero2, phin = zero2;
 #if !LDPC_RES_NO_PLAN_PREFETCH                        // tuning builds with more waves per SIMD trade the prefetch for registers
         if (qn < n) {
             metan = pl.vmeta[qn];
-            slon = pl.vslot_lo[qn];
-            if (wide) shin = pl.vslot_hi[qn];
+            plon = pl.vslot_lo[qn];
+            if (qn < n_hi) phin = pl.vslot_hi[qn];
         }
 #endif
         const int dv = (int)(meta & 0xffu);
+        const uint4 slo = plan_unpack(plo), shi = plan_unpack(phi);
         T a = (T)0;                                                      // LDS copy of the table when small
         if (MODE == 0 || MODE == 4) a = alpha_lds ? alpha_lds[meta >> 8] : alpha_glb[meta >> 8];
         // one scalar branch into the body of the wave's degree; a class-boundary wave (two or three degrees)
@@ -677,11 +690,11 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
 #if LDPC_RES_NO_PLAN_PREFETCH
         if (qn < n) {
             metan = pl.vmeta[qn];
-            slon = pl.vslot_lo[qn];
-            if (wide) shin = pl.vslot_hi[qn];
+            plon = pl.vslot_lo[qn];
+            if (qn < n_hi) phin = pl.vslot_hi[qn];
         }
 #endif
-        q = qn; meta = metan; slo = slon; shi = shin;
+        q = qn; meta = metan; plo = plon; phi = phin;
     }
 }
 
@@ -882,11 +895,12 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
     T *alpha_s = reinterpret_cast<T *>(res_smem + res_off_alpha(pl.S, pl.n, GE));
     uint8_t *bits_s = res_smem + res_off_bits(pl.S, pl.n, GE, n_alpha_lds);
     unsigned *sh_unsat = reinterpret_cast<unsigned *>(res_smem + res_off_flag(pl.S, pl.n, GE, n_alpha_lds));
-    ParScatter ps;
-    if (ES && pl.par_words) {
-        ps.par_off = (unsigned)res_off_par(pl.S, pl.n, GE, n_alpha_lds);
-        ps.shift = (unsigned)pl.par_shift;
-        ps.mask = (unsigned)pl.mstride - 1u;
+    ParScatter ps, psf;                                  // per-iteration syndrome (early stop) / final syndrome (fixed T)
+    if (pl.par_words) {
+        psf.par_off = (unsigned)res_off_par(pl.S, pl.n, GE, n_alpha_lds);
+        psf.shift = (unsigned)pl.par_shift;
+        psf.mask = (unsigned)pl.mstride - 1u;
+        if (ES) ps = psf;
     }
     const T *g_llr = reinterpret_cast<const T *>(a.llr);
     const T *g_beta = reinterpret_cast<const T *>(a.beta);
@@ -924,32 +938,32 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
     }
     for (int k = tid; k < (a.alpha_in_lds ? a.T * a.n_alpha : 0); k += nt) alpha_s[k] = g_alpha[k];
     if (tid == 0) { sh_unsat[0] = 0; sh_unsat[1] = 0; }
-    if (ES)
-        for (int k = tid; k < pl.par_words; k += nt) lds_store<unsigned>(ps.par_off + 4u * (unsigned)k, 0u);
+    for (int k = tid; k < pl.par_words; k += nt) lds_store<unsigned>(psf.par_off + 4u * (unsigned)k, 0u);
     __syncthreads();
     // "initialise v2c with the channel LLRs" (T == 0: c2v = 0, the loop never runs)
     {
         const P *L = reinterpret_cast<const P *>(llr_s);
         for (int q0 = tid; q0 < n && !LDPC_PROBE(a, 32); q0 += kPro * nt) {
             int dvk[kPro];
-            uint4 slo[kPro], shi[kPro];
+            uint2 plo[kPro], phi[kPro];
 #pragma unroll
             for (int k = 0; k < kPro; ++k) {                       // plan loads of the whole batch first
                 const int q = q0 + k * nt;
                 dvk[k] = 0;
-                slo[k] = make_uint4(0, 0, 0, 0);
-                shi[k] = make_uint4(0, 0, 0, 0);
+                plo[k] = make_uint2(0, 0);
+                phi[k] = make_uint2(0, 0);
                 if (q < n) {
                     dvk[k] = (int)(pl.vmeta[q] & 0xffu);
-                    slo[k] = pl.vslot_lo[q];
-                    if (pl.max_dv > 4) shi[k] = pl.vslot_hi[q];
+                    plo[k] = pl.vslot_lo[q];
+                    if (q < pl.n_hi) phi[k] = pl.vslot_hi[q];
                 }
             }
 #pragma unroll
             for (int k = 0; k < kPro; ++k) {
                 const int q = q0 + k * nt;
                 if (q < n) {
-                    const unsigned off[8] = {slo[k].x, slo[k].y, slo[k].z, slo[k].w, shi[k].x, shi[k].y, shi[k].z, shi[k].w};
+                    const uint4 slo = plan_unpack(plo[k]), shi = plan_unpack(phi[k]);
+                    const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
                     P l = L[q];
                     if (a.T == 0) {
 #pragma unroll
@@ -1051,14 +1065,20 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
         res_emit_bits<G>(pl, a, bits_s, b0, open, a.T, kAll, tid, nt);
         return;
     }
+    // fixed-T mode: success = final syndrome is zero.  With parity words (power-of-two stride) the posterior pass scatters the
+    // decisions into them (one LDS atomic per edge, then m words are read); otherwise the decisions go into the dead message
+    // slots and every check reads its row of them back (MODE 8 / res_syndrome_slots)
+    const bool scatter = LDPC_RES_FINAL_SCATTER && !ES && psf.par_off != 0;
     if (!LDPC_PROBE(a, 8)) {
         if (ES) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, open, tid, nt);
+        else if (scatter) res_var_phase<G, 1, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, open, tid, nt, psf);
         else res_var_phase<G, 8, T>(pl, res_smem, llr_s, bits_s, (const T *)nullptr, (const T *)nullptr, open, tid, nt);
     }
     __syncthreads();
     unsigned unsat = kAll;
-    if (!ES && !LDPC_PROBE(a, 8)) {                    // fixed-T mode: success = final syndrome is zero
-        res_syndrome_slots<G, T, SPLIT>(pl, sh_unsat, tid, nt);
+    if (!ES && !LDPC_PROBE(a, 8)) {
+        if (scatter) res_parity_reduce<G, SPLIT>(pl, psf.par_off, sh_unsat, tid, nt);
+        else res_syndrome_slots<G, T, SPLIT>(pl, sh_unsat, tid, nt);
         __syncthreads();
         unsat = *sh_unsat;
     }
