@@ -128,6 +128,30 @@ __device__ __forceinline__ void lds_store(unsigned byte_off, const X &v)
     *(LP)(size_t)byte_off = u.v;
 }
 
+// LLRs in and decisions out are touched once per codeword: non-temporal, so that they do not evict the plan (the index data
+// every iteration re-reads) from the CU's L1
+#ifndef LDPC_RES_NT_IO
+#define LDPC_RES_NT_IO 1
+#endif
+template <typename X>
+__device__ __forceinline__ X res_stream_load(const X *p)
+{
+#if LDPC_RES_NT_IO
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename X>
+__device__ __forceinline__ void res_stream_store(X *p, X v)
+{
+#if LDPC_RES_NT_IO
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ void lds_atomic_xor(unsigned byte_off, unsigned v)
 {
     using LP = __attribute__((address_space(3))) unsigned *;
@@ -795,8 +819,8 @@ __device__ __forceinline__ void res_emit(const ResidentPlan &pl, const ResidentA
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     if (!((mask >> g) & 1u)) continue;
-                    if (in && a.posterior) posterior[(size_t)(b0 + g) * n + j] = p.x[g];
-                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = p.x[g] < (T)0 ? 1 : 0;
+                    if (in && a.posterior) res_stream_store(&posterior[(size_t)(b0 + g) * n + j], p.x[g]);
+                    if (in && a.bits) res_stream_store(&a.bits[(size_t)(b0 + g) * n + j], p.x[g] < (T)0 ? 1 : 0);
                     if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && p.x[g] < (T)0);
                 }
             }
@@ -833,7 +857,7 @@ __device__ __forceinline__ void res_emit_bits(const ResidentPlan &pl, const Resi
                 for (int g = 0; g < G; ++g) {
                     if (!((mask >> g) & 1u)) continue;
                     const unsigned bit = (bb >> g) & 1u;
-                    if (in && a.bits) a.bits[(size_t)(b0 + g) * n + j] = (int)bit;
+                    if (in && a.bits) res_stream_store(&a.bits[(size_t)(b0 + g) * n + j], (int)bit);
                     if (a.packed) res_store_packed<G>(a, b0 + g, j, n, in && bit != 0);
                 }
             }
@@ -928,7 +952,7 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
                     ip[k] = pl.inv_perm_v[j];
 #pragma unroll
                     for (int g = 0; g < G; ++g)
-                        v[k].x[g] = (b0 + g < a.batch) ? g_llr[(size_t)(b0 + g) * n + j] : (T)1;
+                        v[k].x[g] = (b0 + g < a.batch) ? res_stream_load(&g_llr[(size_t)(b0 + g) * n + j]) : (T)1;
                 }
             }
 #pragma unroll
