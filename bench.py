@@ -230,6 +230,34 @@ def stream_roofline(engine, workload, g, T, B, llr, reps, copy_gbs, torch):
         for _ in range(3):
             engine.debug_sweep(B, which, it)
         times[name] = event_ms(lambda: engine.debug_sweep(B, which, it), reps, torch)
+    if info.get("stream_form") == "rcq-code-pair" and 1 <= it < T - 1:
+        # Both directions are 1-byte codes: the check sweep reads and writes E bytes per codeword (integer-only), the
+        # variable sweep reads E code bytes + the 4n LLR bytes and writes E bytes, quantising with the next iteration's
+        # beta and thresholds.  The variable sweep is the longer of the two and the roofline entry; the pair is one
+        # iteration (4E + 4n bytes per codeword against 10E + 4n of the fp32-V2C formulation).
+        cn_b, vn_b = 2 * g.E * B, (2 * g.E + 4 * g.n) * B
+        ach = vn_b / (times["vn"] * 1e-3) / 1e9
+        tr, src = traffic_of(db, "vn_sweep_q4", workload, B)
+        trc, srcc = traffic_of(db, "cn_sweep_q4", workload, B)
+        t_it = times["cn"] + times["vn"]
+        return {"bound": "hbm", "kernel": "ldpc::vn_sweep_q4 (variable sweep of the RCQ code-pair form: C2V codes + LLRs in, V2C codes "
+                                          "out; streaming engine)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": vn_b, "ms_per_launch": times["vn"],
+                "traffic": tr, "traffic_source": src,
+                "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": ach / copy_gbs if copy_gbs else None,
+                "cn_sweep_q4": {"ms_per_launch": times["cn"], "algorithmic_bytes_per_launch": cn_b,
+                                "achieved": cn_b / (times["cn"] * 1e-3) / 1e9,
+                                "frac": cn_b / (times["cn"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": trc, "traffic_source": srcc},
+                "iteration": {"ms": t_it, "algorithmic_bytes": cn_b + vn_b,
+                              "achieved": (cn_b + vn_b) / (t_it * 1e-3) / 1e9,
+                              "frac": (cn_b + vn_b) / (t_it * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "hbm_formulation_equiv": {"bytes_per_launch": bm["iteration"],
+                                          "achieved": bm["iteration"] / (t_it * 1e-3) / 1e9,
+                                          "frac": bm["iteration"] / (t_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "SURVEY 8d bytes of one iteration in the fp32-V2C two-sweep formulation (10E+4n per "
+                                                  "codeword) over this form's cn + vn time"}}
     if info.get("stream_form") == "fused-rcq-iteration" and it >= 1:
         # One kernel = one whole iteration.  ALGORITHMIC bytes of this formulation: per edge the LLR of its variable (4 B)
         # and the codes of the variable's OTHER edges (dv-1 B) are read, one code byte is written -- 4E + sum_j dv(dv-1) + E

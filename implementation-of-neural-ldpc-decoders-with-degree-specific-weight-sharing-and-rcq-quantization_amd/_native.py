@@ -26,7 +26,7 @@ DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "ldpc_hip_debug.h
 
 LDPC_F32, LDPC_F64 = 0, 1
 C2V_NMS, C2V_RCQ, C2V_OMS = 0, 1, 2
-MODE_AUTO, MODE_STREAM, MODE_RESIDENT, MODE_SWEEPS = 0, 1, 2, 3
+MODE_AUTO, MODE_STREAM, MODE_RESIDENT, MODE_SWEEPS, MODE_GATHER, MODE_PAIR = 0, 1, 2, 3, 4, 5
 SCHED_FLOODING, SCHED_LAYERED_REF, SCHED_LAYERED = 0, 1, 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -109,15 +109,18 @@ struct ldpc_decoder {
     // fused RCQ iteration of the streaming engine (cn_gather): per-edge gather metadata, built at creation for fp32
     // flooding RCQ decoders on graphs with variable degree <= 8
     bool gat_ok = false;
+    bool pair_ok = false;          // RCQ code-pair form (vn_sweep_q / cn_sweep_q): one beta per check, sorted thresholds
     int4 *gat_meta = nullptr;      // [E + 1]
     int *gat_nbr = nullptr;        // [sum dv(dv-1) + 8]
 };
 
 namespace {
 
-bool use_resident(const ldpc_decoder *d) { return d->res_ok && d->mode != LDPC_MODE_STREAM && d->mode != LDPC_MODE_SWEEPS; }
+bool use_resident(const ldpc_decoder *d) { return d->res_ok && (d->mode == LDPC_MODE_AUTO || d->mode == LDPC_MODE_RESIDENT); }
 // streaming engine, RCQ: one fused kernel per iteration (cn_gather) unless the two-sweep form is forced
-bool use_gather(const ldpc_decoder *d) { return d->gat_ok && d->mode != LDPC_MODE_SWEEPS; }
+// streaming forms of an fp32 RCQ decoder, best first: code pair (4E + 4n bytes per iteration), fused gather, two sweeps
+bool use_pair(const ldpc_decoder *d) { return d->pair_ok && d->mode != LDPC_MODE_SWEEPS && d->mode != LDPC_MODE_GATHER; }
+bool use_gather(const ldpc_decoder *d) { return d->gat_ok && !use_pair(d) && d->mode != LDPC_MODE_SWEEPS && d->mode != LDPC_MODE_PAIR; }
 
 // tile width: 64 lanes x VEC codewords.  fp32: VEC 4 (16 B per lane) for real batches,
 // VEC 1 for latency-mode batches <= 64; fp64: VEC 2 / 1.
@@ -156,7 +159,7 @@ Workspace carve(const ldpc_decoder *d, int64_t batch, void *base)
         return o;
     };
     const size_t o_llr = take(tw * n * es);
-    const size_t o_v2c = take(tw * std::max<size_t>(E, 1) * (use_gather(d) ? 1 : es));   // gather form: the second code buffer
+    const size_t o_v2c = take(tw * std::max<size_t>(E, 1) * ((use_gather(d) || use_pair(d)) ? 1 : es));   // gather / code-pair form: the second code buffer
     const size_t o_c2v = take(tw * std::max<size_t>(E, 1) * (d->form == LDPC_C2V_RCQ ? 1 : es));
     const size_t o_post = take(tw * n * es);
     const size_t o_bits = take((size_t)w.tiles * n * w.vec * sizeof(uint64_t));
@@ -273,6 +276,84 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
         if (last) LDPC_VN(false, true); else LDPC_VN(false, false);
     }
 #undef LDPC_VN
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+// code-pair form, iterations >= 1: V2C codes (w.v2c) -> C2V codes (w.c2v)
+template <int VEC>
+int launch_cn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
+{
+    const GraphDev g = d->g->dev();
+    const int dmax = d->g->max_dc;
+    const int cpw = (dmax <= 8 && g.E < 8 * (long long)g.m) ? 2 : 1;
+    const int per_block = kWavesPerBlock * cpw;
+    const int cb = (g.m + per_block - 1) / per_block;
+    if (cb == 0 || g.E == 0) return LDPC_OK;
+    const dim3 grid((unsigned)((size_t)w.tiles * cb)), block(kBlock);
+    const float *beta_row = (const float *)d->beta + (size_t)it * d->n_beta;
+    const float *thr = d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels;
+    const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_CQ(CPW_, DCMAX_)                                                                                        \
+    hipLaunchKernelGGL((cn_sweep_q<VEC, CPW_, DCMAX_>), grid, block, 0, s, g, (const uint8_t *)w.v2c, (uint8_t *)w.c2v, \
+                       beta_row, (const int *)d->beta_slot, thr, d->n_levels, done, cb)
+#define LDPC_CQ4(CPW_, DCMAX_)                                                                                       \
+    do {                                                                                                             \
+        if (done)                                                                                                    \
+            hipLaunchKernelGGL((cn_sweep_q4<CPW_, DCMAX_, true>), grid, block, 0, s, g, (const uint8_t *)w.v2c,       \
+                               (uint8_t *)w.c2v, beta_row, (const int *)d->beta_slot, d->n_levels, done, cb);        \
+        else                                                                                                         \
+            hipLaunchKernelGGL((cn_sweep_q4<CPW_, DCMAX_, false>), grid, block, 0, s, g, (const uint8_t *)w.v2c,      \
+                               (uint8_t *)w.c2v, beta_row, (const int *)d->beta_slot, d->n_levels, done, cb);        \
+    } while (0)
+    if constexpr (VEC == 4) {
+        if (dmax <= 8) { if (cpw == 2) LDPC_CQ4(2, 8); else LDPC_CQ4(1, 8); }
+        else if (dmax <= 16) LDPC_CQ4(1, 16);
+        else if (dmax <= 32) LDPC_CQ4(1, 32);
+        else LDPC_CQ4(1, 0);
+    } else {
+        if (dmax <= 8) { if (cpw == 2) LDPC_CQ(2, 8); else LDPC_CQ(1, 8); }
+        else if (dmax <= 16) LDPC_CQ(1, 16);
+        else if (dmax <= 32) LDPC_CQ(1, 32);
+        else LDPC_CQ(1, 0);
+    }
+#undef LDPC_CQ4
+#undef LDPC_CQ
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+// code-pair form, iterations < T-1: C2V codes of iteration `it` (w.c2v) -> V2C codes for iteration it + 1 (w.v2c)
+template <int VEC>
+int launch_vn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
+{
+    const GraphDev g = d->g->dev();
+    const int vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid((unsigned)((size_t)w.tiles * vb)), block(kBlock);
+    const float *alpha_row = (const float *)d->alpha + (size_t)it * d->n_alpha;
+    const float *beta_next = (const float *)d->beta + (size_t)(it + 1) * d->n_beta;
+    const float *thr_next = d->thresholds + (size_t)d->q_of_iter[it + 1] * d->n_levels;
+    const int lut_entries = 2 * d->n_levels;
+    const float *lut_cur = d->lut + (size_t)d->q_of_iter[it] * lut_entries;
+    const size_t shmem = (size_t)lut_entries * sizeof(float);
+    const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_VQ(NL_)                                                                                                  \
+    hipLaunchKernelGGL((vn_sweep_q<VEC, NL_>), grid, block, shmem, s, g, (const uint8_t *)w.c2v, (const float *)w.llrT, \
+                       (uint8_t *)w.v2c, alpha_row, (const int *)d->alpha_slot, lut_cur, lut_entries, beta_next,        \
+                       (const int *)d->beta_slot, thr_next, d->n_levels, w.bitsT, done, vb)
+    const int vb4 = (g.n + kWavesPerBlock * LDPC_VNQ_VPW - 1) / (kWavesPerBlock * LDPC_VNQ_VPW);
+    const dim3 grid4((unsigned)((size_t)w.tiles * vb4));
+#define LDPC_VQ4(NL_, ES_)                                                                                            \
+    hipLaunchKernelGGL((vn_sweep_q4<NL_, ES_, LDPC_VNQ_VPW>), grid4, block, shmem, s, g, (const uint8_t *)w.c2v,         \
+                       (const float *)w.llrT, (uint8_t *)w.v2c, alpha_row, (const int *)d->alpha_slot, lut_cur,         \
+                       lut_entries, beta_next, (const int *)d->beta_slot, thr_next, d->n_levels, w.bitsT, done, vb4)
+    if (VEC == 4 && d->g->max_dv <= 8 && d->n_levels <= 8) {
+        if (d->n_levels == 4) { if (done) LDPC_VQ4(4, true); else LDPC_VQ4(4, false); }
+        else { if (done) LDPC_VQ4(0, true); else LDPC_VQ4(0, false); }
+    }
+    else if (d->n_levels == 4) LDPC_VQ(4); else LDPC_VQ(0);
+#undef LDPC_VQ4
+#undef LDPC_VQ
     HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }
@@ -398,7 +479,23 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         int rc = launch_vn<T, VEC>(d, w, 0, /*last=*/true, /*use_done=*/false, s);
         if (rc) return rc;
     }
-    if (use_gather(d) && !saved) {
+    if (use_pair(d) && !saved) {
+        if constexpr (sizeof(T) == 4) {
+            // RCQ, code-pair form: iteration 0 is the plain check sweep on the LLRs; after that both directions are
+            // 1-byte codes (vn_sweep_q quantises with the next iteration's beta and thresholds, cn_sweep_q is integer-only);
+            // the last variable pass is the ordinary posterior pass over the C2V codes.
+            for (int it = 0; it < T_it; ++it) {
+                int rc = it == 0 ? launch_cn<T, VEC>(d, w, 0, early_stop, s) : launch_cn_q<VEC>(d, w, it, early_stop, s);
+                if (rc) return rc;
+                rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s)
+                                    : launch_vn_q<VEC>(d, w, it, early_stop, s);
+                if (rc) return rc;
+                if (early_stop)
+                    hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
+                                       w.iters, it + 1, 1);
+            }
+        }
+    } else if (use_gather(d) && !saved) {
         if constexpr (sizeof(T) == 4) {
             // RCQ, fused form: iteration 0 is the plain check sweep on the LLRs, every later iteration ONE cn_gather
             // launch (codes ping-pong between the two code buffers; iteration `it` writes buffer it & 1).  The hard
@@ -1092,6 +1189,19 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
         if (!rc) rc = upload(&d->gat_nbr, nbr.data(), nbr.size());
         d->gat_ok = !rc;
     }
+    if (!rc && d->form == LDPC_C2V_RCQ && d->dtype == LDPC_F32 && d->schedule == LDPC_SCHED_FLOODING && g->E > 0 &&
+        d->beta_per_check && d->n_levels <= 62) {
+        // code-pair form: level(|beta * x|) must be non-decreasing in x, i.e. thresholds 1.. of every quantiser sorted, and
+        // positive (level(0) = 0; the magnitude compares run on the bit patterns)
+        // (threshold 0 never decides a level, rcq_decoder.py:79-85)
+        bool sorted = true;
+        for (int q = 0; q < d->n_quant && sorted; ++q)
+            for (int k = 1; k < d->n_levels; ++k) {
+                const float t = desc->thresholds[(size_t)q * d->n_levels + k];
+                if (!(t > 0.0f) || (k > 1 && t < desc->thresholds[(size_t)q * d->n_levels + k - 1])) { sorted = false; break; }
+            }
+        d->pair_ok = sorted;
+    }
     resident_table_flags(d, desc->alpha, d->form == LDPC_C2V_RCQ ? desc->thresholds : nullptr);
     if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
     if (rc) {
@@ -1110,7 +1220,12 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
 int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
 {
     if (!d) return fail(LDPC_ERR_ARG, "NULL decoder");
-    if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_SWEEPS) return fail(LDPC_ERR_ARG, "bad mode");
+    if (mode < LDPC_MODE_AUTO || mode > LDPC_MODE_PAIR) return fail(LDPC_ERR_ARG, "bad mode");
+    if (mode == LDPC_MODE_GATHER && !d->gat_ok)
+        return fail(LDPC_ERR_UNSUPPORTED, "the fused RCQ iteration needs an fp32 flooding RCQ decoder with variable degree <= 8");
+    if (mode == LDPC_MODE_PAIR && !d->pair_ok)
+        return fail(LDPC_ERR_UNSUPPORTED, "the code-pair form needs an fp32 flooding RCQ decoder with one beta per check, "
+                                          "sorted thresholds and at most 62 levels");
     if (mode == LDPC_MODE_RESIDENT && !d->res_ok)
         return fail(LDPC_ERR_UNSUPPORTED, "code does not qualify for the LDS-resident engine "
                                           "(dv <= 8, check degree <= 1024, state within 160 KiB of LDS)");
@@ -1121,7 +1236,7 @@ int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
 int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4])
 {
     if (!d || !out4) return fail(LDPC_ERR_ARG, "NULL argument");
-    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : (use_gather(d) ? LDPC_MODE_STREAM : LDPC_MODE_SWEEPS);
+    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : use_pair(d) ? LDPC_MODE_PAIR : use_gather(d) ? LDPC_MODE_GATHER : LDPC_MODE_SWEEPS;
     out4[1] = d->res_ok ? (d->dtype == LDPC_F64 ? 1 : d->res_G) : 0;      // fp64: one codeword in a float pair's slots
     out4[2] = d->res_ok ? d->res_NT : 0;
     out4[3] = d->res_ok ? (int32_t)d->res_lds : 0;
@@ -1404,6 +1519,12 @@ int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_
     DeviceGuard guard(d->g->device);
     hipStream_t s = (hipStream_t)stream;
     const bool f64 = d->dtype == LDPC_F64;
+    if (use_pair(d) && !f64) {
+        // code-pair form: which = 0 the check sweep (integer-only from iteration 1), which = 1 the variable sweep
+        // (code-producing except in the last iteration)
+        if (which == 0 && iter >= 1) return w.vec == 1 ? launch_cn_q<1>(d, w, iter, false, s) : launch_cn_q<4>(d, w, iter, false, s);
+        if (which != 0 && iter < d->T - 1) return w.vec == 1 ? launch_vn_q<1>(d, w, iter, false, s) : launch_vn_q<4>(d, w, iter, false, s);
+    }
     if (use_gather(d) && !f64) {
         // fused RCQ form: which = 0 is the fused iteration kernel (iter >= 1; iteration 0 is the plain check sweep),
         // which = 1 the posterior-only variable pass

@@ -802,6 +802,529 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
 }
 
 // ------------------------------------------------------------------------------------------
+// RCQ with ONE beta per check, "code pair" form: BOTH message directions travel as one byte per edge.
+//
+// The check update of iteration t+1 (rcq_decoder.py:242-246 / :559-563) sees a variable->check message v only through
+//   sign(v)   and   level_{t+1}(| beta * min_{others} |v| |),
+// and with one beta per check and non-decreasing thresholds  x -> level(|beta * x|)  is non-decreasing in x, so
+//   level(|beta * min_u |v_u||) = min_u level(|beta * |v_u||)        (exactly: the same float product is rounded).
+// The variable sweep therefore applies the NEXT iteration's beta and quantiser to each outgoing value itself and stores
+//   byte = key | sign << 6,   key = 0 when |beta * |v|| is not > 0 (zero / underflow: the check output is code
+//                             level(0), its sign bit cleared, rcq_decoder.py:88),  else 1 + level(|beta * |v||)
+// and the check sweep is integer-only: min1 / min2 of the keys, XOR of the sign bits, one table-free code per edge.
+// Per codeword and iteration: 4E + 4n bytes (E = both code arrays read and written once, 4n the LLR rows) against
+// 10E + 4n for the fp32 V2C array and 5E + sum dv(dv-1) issued by the gather form.
+// Iteration 0 stays cn_sweep<FIRST> on the LLR rows, the last variable pass stays vn_sweep<CODES, LAST>.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned kKeyMask = 63u;          // n_levels <= 62 (host check)
+
+template <int NL>
+__device__ __forceinline__ unsigned v2c_code(float val, float b, const float (&th)[8], const float *thr, int n_levels)
+{
+    const float mag = __builtin_fabsf(b * __builtin_fabsf(val));
+    unsigned lvl = 0;
+    if constexpr (NL > 0) {
+#pragma unroll
+        for (int q = 1; q < NL; ++q) lvl = (mag >= th[q]) ? (unsigned)q : lvl;
+    } else if (n_levels <= 8) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) lvl = (mag >= th[q]) ? (unsigned)q : lvl;       // NaN padding never matches
+    } else {
+        for (int q = 1; q < n_levels; ++q) lvl = (mag >= thr[q]) ? (unsigned)q : lvl;
+    }
+    const unsigned key = (mag > 0.0f) ? lvl + 1u : 0u;
+    return key | (signbit_of<float>(val) << 6);
+}
+
+template <int VEC, int NL, int DV>
+__device__ __forceinline__ void vn_q_body(const GraphDev &g, int tile, int j, int s0, int lane,
+                                          const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
+                                          uint8_t *__restrict__ v2c, float a, const Lut<VEC> &lut,
+                                          const float *__restrict__ beta_next, const int *__restrict__ beta_slot,
+                                          const float (&th)[8], const float *__restrict__ thr, int n_levels,
+                                          uint64_t *__restrict__ bitsT, const Frozen<VEC> &fz)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int D = DV > 0 ? DV : 1;
+    const size_t lane_off = (size_t)lane * VEC;
+    const size_t tileE = (size_t)tile * g.E;
+    int e[D];
+    float bb[D];
+    Pack<float, VEC> x[D];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) x[k] = load_c2v<float, VEC, true>(c2v, (tileE + e[k]) * W + lane_off, lut);
+    const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+#pragma unroll
+    for (int k = 0; k < DV; ++k) bb[k] = beta_next[beta_slot[e[k]]];
+
+    Pack<float, VEC> post;
+    Pack<uint8_t, VEC> out[D];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        float xs[D];
+#pragma unroll
+        for (int k = 0; k < DV; ++k) xs[k] = x[k].x[c];
+        post.x[c] = l.x[c] + sum_ct<DV, -1, 0, float>(xs);
+        float v[D];
+        if constexpr (DV >= 1) v[0] = l.x[c] + a * sum_ct<DV - 1, 0, 0, float>(xs);
+        if constexpr (DV >= 2) v[1] = l.x[c] + a * sum_ct<DV - 1, 1, 0, float>(xs);
+        if constexpr (DV >= 3) v[2] = l.x[c] + a * sum_ct<DV - 1, 2, 0, float>(xs);
+        if constexpr (DV >= 4) v[3] = l.x[c] + a * sum_ct<DV - 1, 3, 0, float>(xs);
+        if constexpr (DV >= 5) v[4] = l.x[c] + a * sum_ct<DV - 1, 4, 0, float>(xs);
+        if constexpr (DV >= 6) v[5] = l.x[c] + a * sum_ct<DV - 1, 5, 0, float>(xs);
+        if constexpr (DV >= 7) v[6] = l.x[c] + a * sum_ct<DV - 1, 6, 0, float>(xs);
+        if constexpr (DV >= 8) v[7] = l.x[c] + a * sum_ct<DV - 1, 7, 0, float>(xs);
+#pragma unroll
+        for (int k = 0; k < DV; ++k) out[k].x[c] = (uint8_t)v2c_code<NL>(v[k], bb[k], th, thr, n_levels);
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k) store_masked<uint8_t, VEC>(v2c + (tileE + e[k]) * W + lane_off, out[k], fz);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        uint64_t mask = __ballot(post.x[c] < 0.0f);
+        if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
+    }
+}
+
+// Variable sweep of the code-pair form (not the last one): C2V codes of iteration `it` in, V2C codes for iteration
+// it + 1 out.  `lut_cur` = the 2L signed reconstruction values of iteration it's quantiser; `beta_next` / `thr_next` = row
+// and thresholds of iteration it + 1.
+template <int VEC, int NL>
+__global__ __launch_bounds__(kBlock) void vn_sweep_q(GraphDev g, const uint8_t *__restrict__ c2v,
+                                                     const float *__restrict__ llrT, uint8_t *__restrict__ v2c,
+                                                     const float *__restrict__ alpha_row, const int *__restrict__ alpha_slot,
+                                                     const float *__restrict__ lut_cur, int lut_entries,
+                                                     const float *__restrict__ beta_next, const int *__restrict__ beta_slot,
+                                                     const float *__restrict__ thr_next, int n_levels,
+                                                     uint64_t *__restrict__ bitsT, const uint64_t *__restrict__ done,
+                                                     int var_blocks)
+{
+    constexpr int W = kWave * VEC;
+    extern __shared__ float lut_s[];
+    for (int k = threadIdx.x; k < lut_entries; k += kBlock) lut_s[k] = lut_cur[k];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int j = uni((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
+    if (j >= g.n) return;
+    const int s0 = uni(g.var_ptr[j]);
+    const int dv = uni(g.var_ptr[j + 1]) - s0;
+
+    Frozen<VEC> fz;
+    if (load_frozen<VEC>(done, tile, lane, fz)) return;
+    const float a = alpha_row[alpha_slot[j]];
+    float th[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) th[q] = (q < n_levels) ? thr_next[q] : __builtin_nanf("");
+    Lut<VEC> lut;
+    lut.base = lut_s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) lut.off[c] = 0;
+
+#define LDPC_VQ_CASE(D) \
+    case D: vn_q_body<VEC, NL, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut, beta_next, beta_slot, th, thr_next, n_levels, bitsT, fz); break;
+    switch (dv) {
+        LDPC_VQ_CASE(0) LDPC_VQ_CASE(1) LDPC_VQ_CASE(2) LDPC_VQ_CASE(3) LDPC_VQ_CASE(4)
+        LDPC_VQ_CASE(5) LDPC_VQ_CASE(6) LDPC_VQ_CASE(7) LDPC_VQ_CASE(8)
+    default: {
+        const size_t lane_off = (size_t)lane * VEC;
+        const size_t tileE = (size_t)tile * g.E;
+        const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+        auto fetch = [&](int k) {
+            return load_c2v<float, VEC, true>(c2v, (tileE + g.csc_edge[s0 + k]) * W + lane_off, lut);
+        };
+        Pack<float, VEC> post = sum_rt<0, float, VEC>(dv, fetch);
+        for (int k = 0; k < dv; ++k) {
+            auto others = [&](int u) { return fetch(u < k ? u : u + 1); };
+            const Pack<float, VEC> sm = sum_rt<0, float, VEC>(dv - 1, others);
+            const int e = g.csc_edge[s0 + k];
+            const float b = beta_next[beta_slot[e]];
+            Pack<uint8_t, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) o.x[c] = (uint8_t)v2c_code<NL>(l.x[c] + a * sm.x[c], b, th, thr_next, n_levels);
+            store_masked<uint8_t, VEC>(v2c + (tileE + e) * W + lane_off, o, fz);
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            uint64_t mask = __ballot(l.x[c] + post.x[c] < 0.0f);
+            if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
+        }
+    }
+    }
+#undef LDPC_VQ_CASE
+}
+
+// Check sweep of the code-pair form (iterations >= 1): V2C codes in, C2V codes out, integer arithmetic only.
+// DCMAX > 0: the check's rows stay in registers between the two passes (graphs with max check degree <= DCMAX);
+// DCMAX == 0: any degree, pass 2 re-reads the row it is about to answer.
+template <int VEC, int CPW, int DCMAX>
+__global__ __launch_bounds__(kBlock) void cn_sweep_q(GraphDev g, const uint8_t *__restrict__ v2c,
+                                                     uint8_t *__restrict__ c2v_out, const float *__restrict__ beta_row,
+                                                     const int *__restrict__ beta_slot, const float *__restrict__ thr,
+                                                     int n_levels, const uint64_t *__restrict__ done, int check_blocks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int R = DCMAX > 0 ? DCMAX : 1;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / check_blocks);
+    const int ibase = uni(((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
+    if (ibase >= g.m) return;
+    Frozen<VEC> fz;
+    if (load_frozen<VEC>(done, tile, lane, fz)) return;
+    constexpr unsigned lvl0 = 0;                       // level(0): thresholds 1.. are > 0 (host check)
+    const size_t lane_off = (size_t)lane * VEC;
+
+#pragma unroll
+    for (int cc_ = 0; cc_ < CPW; ++cc_) {
+        const int i = ibase + cc_;
+        if (i >= g.m) break;
+        const int e0 = uni(g.check_ptr[i]);
+        const int dc = uni(g.check_ptr[i + 1]) - e0;
+        if (dc == 0) continue;
+        const uint8_t *in_base = v2c + ((size_t)tile * g.E + e0) * W + lane_off;
+        uint8_t *out_base = c2v_out + ((size_t)tile * g.E + e0) * W + lane_off;
+        const unsigned sgn_b = signbit_of<float>(beta_row[beta_slot[e0]]) ? (unsigned)n_levels : 0u;   // sign of beta * min
+
+        Pack<uint8_t, VEC> in[R];
+        unsigned m1[VEC], m2[VEC], par[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { m1[c] = 255u; m2[c] = 255u; par[c] = 0; }
+        if constexpr (DCMAX > 0) {
+#pragma unroll
+            for (int t = 0; t < DCMAX; ++t)
+                if (t < dc) in[t] = ld<uint8_t, VEC>(in_base + (size_t)t * W);
+#pragma unroll
+            for (int t = 0; t < DCMAX; ++t) {
+                if (t < dc) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+                        const unsigned q = in[t].x[c], key = q & kKeyMask;
+                        par[c] ^= q;
+                        m2[c] = min(m2[c], max(m1[c], key));
+                        m1[c] = min(m1[c], key);
+                    }
+                }
+            }
+        } else {
+#pragma unroll LDPC_CN_UNROLL
+            for (int t = 0; t < dc; ++t) {
+                const Pack<uint8_t, VEC> v = ld<uint8_t, VEC>(in_base + (size_t)t * W);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const unsigned q = v.x[c], key = q & kKeyMask;
+                    par[c] ^= q;
+                    m2[c] = min(m2[c], max(m1[c], key));
+                    m1[c] = min(m1[c], key);
+                }
+            }
+        }
+        if (dc == 1) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) m2[c] = m1[c];       // "min2_val = min_val" (rcq_decoder.py:233-234)
+        }
+        auto emit = [&](int t, const Pack<uint8_t, VEC> &own) {
+            Pack<uint8_t, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const unsigned q = own.x[c], key = q & kKeyMask;
+                const unsigned k = (key == m1[c]) ? m2[c] : m1[c];            // min over the OTHER edges (ties: m2 == m1)
+                const unsigned neg = ((par[c] ^ q) >> 6) & 1u;                 // sign parity of the others
+                const unsigned sgn = neg ? ((unsigned)n_levels - sgn_b) : sgn_b;   // (w < 0) * L
+                o.x[c] = (uint8_t)(k == 0u ? lvl0 : k - 1u + sgn);
+            }
+            store_masked<uint8_t, VEC>(out_base + (size_t)t * W, o, fz);
+        };
+        if constexpr (DCMAX > 0) {
+#pragma unroll
+            for (int t = 0; t < DCMAX; ++t)
+                if (t < dc) emit(t, in[t]);
+        } else {
+#pragma unroll LDPC_CN_UNROLL
+            for (int t = 0; t < dc; ++t) emit(t, ld<uint8_t, VEC>(in_base + (size_t)t * W));
+        }
+    }
+}
+
+// ---- 256-codeword tiles (VEC = 4): the four codewords of a lane are the four bytes of one dword, and both sweeps
+// work on the dword where they can (the generic kernels above spend 13 / 25 VALU instructions per codeword and edge,
+// which is more than the byte traffic leaves room for; these take ~6 / ~15).
+// ES = false (fixed iteration count): no latch words, plain stores, no per-iteration hard decisions.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <bool ES>
+__device__ __forceinline__ void store_codes4(uint8_t *p, unsigned o, const Frozen<4> &fz)
+{
+    if constexpr (ES) store_masked<uint8_t, 4>(p, __builtin_bit_cast(Pack<uint8_t, 4>, o), fz);
+    else st<uint8_t, 4>(p, __builtin_bit_cast(Pack<uint8_t, 4>, o));
+}
+
+// Check sweep, VEC = 4.  Keys of codewords 0/2 and 1/3 sit in the 16-bit halves of two registers (v_pk_min/max_u16);
+// the four possible answers of a check -- (min over others = m1 | m2) x (sign parity of the others 0 | 1) -- are built once
+// per check as byte vectors, and every edge picks per byte with three v_perm_b32 (parity of the others, own key == m1).
+// Thresholds 1.. are > 0 (host check), so a zero-magnitude output is code 0.
+// DC > 0: exactly DC edges, straight-line code (DCMAX <= 8 graphs: one body per degree); DC == 0: up to DCMAX edges under
+// `t < dc` predicates (DCMAX 16 / 32), or any degree with the rows re-read in pass 2 (DCMAX == 0).
+template <int DC, int DCMAX, bool ES>
+__device__ __forceinline__ void cn_q4_check(int dc, const uint8_t *__restrict__ in_base, uint8_t *__restrict__ out_base,
+                                            unsigned s_pos, unsigned s_neg, const Frozen<4> &fz)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    constexpr int R = DC > 0 ? DC : (DCMAX > 0 ? DCMAX : 1);
+    constexpr bool HELD = DC > 0 || DCMAX > 0;
+    auto row = [](const uint8_t *p) { return __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(p)); };
+    auto live = [&](int t) { return DC > 0 ? true : t < dc; };
+    unsigned in[R];
+    unsigned par = 0;
+    u16x2 m1l = as_u16x2(0x00ff00ffu), m2l = m1l, m1h = m1l, m2h = m1l;
+    auto absorb = [&](unsigned q) {
+        const u16x2 kl = as_u16x2(q & 0x003f003fu), kh = as_u16x2((q >> 8) & 0x003f003fu);
+        par ^= q;
+        m2l = __builtin_elementwise_min(m2l, __builtin_elementwise_max(m1l, kl));
+        m1l = __builtin_elementwise_min(m1l, kl);
+        m2h = __builtin_elementwise_min(m2h, __builtin_elementwise_max(m1h, kh));
+        m1h = __builtin_elementwise_min(m1h, kh);
+    };
+    if constexpr (HELD) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (live(t)) in[t] = row(in_base + (size_t)t * W);
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (live(t)) absorb(in[t]);
+    } else {
+#pragma unroll LDPC_CN_UNROLL
+        for (int t = 0; t < dc; ++t) absorb(row(in_base + (size_t)t * W));
+    }
+    if (DC == 1 || (DC == 0 && dc == 1)) { m2l = m1l; m2h = m1h; }       // "min2_val = min_val" (rcq_decoder.py:233-234)
+    // answers: code = 0 for key 0, else key - 1 + (w < 0) * L
+    auto answer = [&](u16x2 kl, u16x2 kh, unsigned sgn) {
+        const u16x2 one = as_u16x2(0x00010001u), s2 = as_u16x2(sgn);
+        const u16x2 al = __builtin_elementwise_sub_sat(kl, one) + __builtin_elementwise_min(kl, one) * s2;
+        const u16x2 ah = __builtin_elementwise_sub_sat(kh, one) + __builtin_elementwise_min(kh, one) * s2;
+        return as_u32(al) | (as_u32(ah) << 8);
+    };
+    const unsigned a1p = answer(m1l, m1h, s_pos), a1n = answer(m1l, m1h, s_neg);
+    const unsigned a2p = answer(m2l, m2h, s_pos), a2n = answer(m2l, m2h, s_neg);
+    const unsigned m1b = as_u32(m1l) | (as_u32(m1h) << 8);
+    auto emit = [&](int t, unsigned q) {
+        const unsigned sel = (((par ^ q) >> 4) & 0x04040404u) | 0x03020100u;            // byte c: c + 4 * parity of the others
+        const unsigned p1 = __builtin_amdgcn_perm(a1n, a1p, sel), p2 = __builtin_amdgcn_perm(a2n, a2p, sel);
+        const unsigned x = ((q & 0x3f3f3f3fu) ^ m1b) + 0x7f7f7f7fu;                   // bit 7 of a byte: own key != m1
+        const unsigned sel2 = ((x >> 5) & 0x04040404u) | 0x03020100u;                   // byte c: c + 4 * (own key != m1)
+        store_codes4<ES>(out_base + (size_t)t * W, __builtin_amdgcn_perm(p1, p2, sel2), fz);
+    };
+    if constexpr (HELD) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+            if (live(t)) emit(t, in[t]);
+    } else {
+#pragma unroll LDPC_CN_UNROLL
+        for (int t = 0; t < dc; ++t) emit(t, row(in_base + (size_t)t * W));
+    }
+}
+
+template <int CPW, int DCMAX, bool ES>
+__global__ __launch_bounds__(kBlock) void cn_sweep_q4(GraphDev g, const uint8_t *__restrict__ v2c,
+                                                      uint8_t *__restrict__ c2v_out, const float *__restrict__ beta_row,
+                                                      const int *__restrict__ beta_slot, int n_levels,
+                                                      const uint64_t *__restrict__ done, int check_blocks)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / check_blocks);
+    const int ibase = uni(((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * CPW);
+    if (ibase >= g.m) return;
+    Frozen<VEC> fz;
+    fz.bits = 0;
+    if constexpr (ES) { if (load_frozen<VEC>(done, tile, lane, fz)) return; }
+    const size_t lane_off = (size_t)lane * VEC;
+
+#pragma unroll
+    for (int cc_ = 0; cc_ < CPW; ++cc_) {
+        const int i = ibase + cc_;
+        if (i >= g.m) break;
+        const int e0 = uni(g.check_ptr[i]);
+        const int dc = uni(g.check_ptr[i + 1]) - e0;
+        if (dc == 0) continue;
+        const uint8_t *in_base = v2c + ((size_t)tile * g.E + e0) * W + lane_off;
+        uint8_t *out_base = c2v_out + ((size_t)tile * g.E + e0) * W + lane_off;
+        const unsigned sb = signbit_of<float>(beta_row[beta_slot[e0]]) ? (unsigned)n_levels : 0u;   // sign of beta * min
+        const unsigned s_pos = sb * 0x00010001u, s_neg = ((unsigned)n_levels - sb) * 0x00010001u;   // (w < 0) * L, both halves
+        if constexpr (DCMAX == 8) {
+#define LDPC_CQ_CASE(D) case D: cn_q4_check<D, 8, ES>(dc, in_base, out_base, s_pos, s_neg, fz); break;
+            switch (dc) {
+                LDPC_CQ_CASE(1) LDPC_CQ_CASE(2) LDPC_CQ_CASE(3) LDPC_CQ_CASE(4)
+                LDPC_CQ_CASE(5) LDPC_CQ_CASE(6) LDPC_CQ_CASE(7) LDPC_CQ_CASE(8)
+            default: break;
+            }
+#undef LDPC_CQ_CASE
+        } else {
+            cn_q4_check<0, DCMAX, ES>(dc, in_base, out_base, s_pos, s_neg, fz);
+        }
+    }
+}
+
+// key of one outgoing value, integer form: the magnitude's bit pattern against the thresholds' (all non-negative, so the
+// unsigned order is the float order; NaN is squashed to 0 first, as `NaN >= tau` and `NaN > 0` are false).
+// NL = 4: three compares into separate lane masks, then three add-with-carry -- hand-scheduled, because a VALU read of a
+// lane mask needs two instructions after the compare that wrote it and the compiler pads every pair with s_nop.
+template <int NL>
+__device__ __forceinline__ unsigned key_of(float val, float b, const unsigned (&tb)[8])
+{
+    const float mag = __builtin_fmaxf(__builtin_fabsf(b * __builtin_fabsf(val)), 0.0f);
+    const unsigned m = __float_as_uint(mag);
+    unsigned key;
+    if constexpr (NL == 4) {
+        unsigned long long c1, c2;
+        asm("v_cmp_le_u32_e64 %1, %4, %3\n\t"
+            "v_cmp_le_u32_e64 %2, %5, %3\n\t"
+            "v_cmp_le_u32_e32 vcc, %6, %3\n\t"
+            "v_min_u32_e32 %0, 1, %3\n\t"
+            "v_addc_co_u32_e64 %0, %1, 0, %0, %1\n\t"
+            "v_addc_co_u32_e64 %0, %2, 0, %0, %2\n\t"
+            "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
+            : "=&v"(key), "=&s"(c1), "=&s"(c2)
+            : "v"(m), "s"(tb[1]), "s"(tb[2]), "s"(tb[3])
+            : "vcc");
+    } else {
+        key = min(m, 1u);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) key += (m >= tb[q]) ? 1u : 0u;                        // NaN padding: above every magnitude
+    }
+    return key;
+}
+
+// the LUT is the only LDS object of vn_sweep_q4 (it starts at LDS address 0): read it by absolute byte offset
+__device__ __forceinline__ float lut_at(unsigned byte_off)
+{
+    return *(__attribute__((address_space(3))) const float *)(size_t)byte_off;
+}
+
+template <int NL, bool ES, int DV>
+__device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int s0, int lane,
+                                           const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
+                                           uint8_t *__restrict__ v2c, float a, const float *lut_s,
+                                           const float *__restrict__ beta_next, const int *__restrict__ beta_slot,
+                                           const unsigned (&tb)[8], uint64_t *__restrict__ bitsT, const Frozen<4> &fz)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    constexpr int D = DV > 0 ? DV : 1;
+    const size_t lane_off = (size_t)lane * VEC;
+    const size_t tileE = (size_t)tile * g.E;
+    int e[D];
+    float bb[D];
+    unsigned q[D];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) q[k] = __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(c2v + (tileE + e[k]) * W + lane_off)) << 2;
+    const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+#pragma unroll
+    for (int k = 0; k < DV; ++k) bb[k] = beta_next[beta_slot[e[k]]];
+
+    unsigned keys[D], sgns[D];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) { keys[k] = 0; sgns[k] = 0; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                 // codewords 2h, 2h + 1 as one float pair (v_pk_add/mul_f32)
+        f32x2 xs[D];
+#pragma unroll
+        for (int k = 0; k < DV; ++k) {            // codes < 16 here: (code << 2) is the byte offset into the LUT
+            xs[k].x = lut_at((q[k] >> (16 * h)) & 0xffu);
+            xs[k].y = lut_at((q[k] >> (16 * h + 8)) & 0xffu);
+        }
+        const f32x2 lh = {l.x[2 * h], l.x[2 * h + 1]};
+        if constexpr (ES) {
+            const f32x2 post = lh + sum_ct<DV, -1, 0, f32x2>(xs);
+            const uint64_t b0 = __ballot(post.x < 0.0f), b1 = __ballot(post.y < 0.0f);
+            if (lane == 0) {
+                bitsT[((size_t)tile * g.n + j) * VEC + 2 * h] = b0;
+                bitsT[((size_t)tile * g.n + j) * VEC + 2 * h + 1] = b1;
+            }
+        }
+        f32x2 v[D];
+        if constexpr (DV >= 1) v[0] = lh + a * sum_ct<DV - 1, 0, 0, f32x2>(xs);
+        if constexpr (DV >= 2) v[1] = lh + a * sum_ct<DV - 1, 1, 0, f32x2>(xs);
+        if constexpr (DV >= 3) v[2] = lh + a * sum_ct<DV - 1, 2, 0, f32x2>(xs);
+        if constexpr (DV >= 4) v[3] = lh + a * sum_ct<DV - 1, 3, 0, f32x2>(xs);
+        if constexpr (DV >= 5) v[4] = lh + a * sum_ct<DV - 1, 4, 0, f32x2>(xs);
+        if constexpr (DV >= 6) v[5] = lh + a * sum_ct<DV - 1, 5, 0, f32x2>(xs);
+        if constexpr (DV >= 7) v[6] = lh + a * sum_ct<DV - 1, 6, 0, f32x2>(xs);
+        if constexpr (DV >= 8) v[7] = lh + a * sum_ct<DV - 1, 7, 0, f32x2>(xs);
+#pragma unroll
+        for (int k = 0; k < DV; ++k) {
+            const unsigned k0 = key_of<NL>(v[k].x, bb[k], tb), k1 = key_of<NL>(v[k].y, bb[k], tb);
+            const unsigned u0 = __float_as_uint(v[k].x), u1 = __float_as_uint(v[k].y);
+            if (h == 0) {
+                keys[k] = k0 | (k1 << 8);
+                sgns[k] = __builtin_amdgcn_perm(u1, u0, 0x0c0c0703u);                       // byte 0 = top of u0, byte 1 = top of u1
+            } else {
+                keys[k] |= (k0 << 16) | (k1 << 24);
+                sgns[k] = __builtin_amdgcn_perm(u0, sgns[k], 0x0c070100u);
+                sgns[k] = __builtin_amdgcn_perm(u1, sgns[k], 0x07020100u);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DV; ++k)
+        store_codes4<ES>(v2c + (tileE + e[k]) * W + lane_off, keys[k] | ((sgns[k] >> 1) & 0x40404040u), fz);
+}
+
+// Variable sweep, VEC = 4, degrees <= 8, at most 8 levels (the host launches vn_sweep_q<4> otherwise).
+// VPW consecutive variables per wave: a degree-2 variable is ~300 instructions of work, less than the wave's prologue
+// (kernel arguments, LUT staging + barrier, thresholds) -- unlike the fp32 sweeps this kernel is not HBM-bound.
+#ifndef LDPC_VNQ_VPW
+#define LDPC_VNQ_VPW 8
+#endif
+template <int NL, bool ES, int VPW>
+__global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t *__restrict__ c2v,
+                                                      const float *__restrict__ llrT, uint8_t *__restrict__ v2c,
+                                                      const float *__restrict__ alpha_row, const int *__restrict__ alpha_slot,
+                                                      const float *__restrict__ lut_cur, int lut_entries,
+                                                      const float *__restrict__ beta_next, const int *__restrict__ beta_slot,
+                                                      const float *__restrict__ thr_next, int n_levels,
+                                                      uint64_t *__restrict__ bitsT, const uint64_t *__restrict__ done,
+                                                      int var_blocks)
+{
+    constexpr int VEC = 4;
+    extern __shared__ float lut_s[];
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();      // lut_at relies on that (folds away)
+    for (int k = threadIdx.x; k < lut_entries; k += kBlock) lut_s[k] = lut_cur[k];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int jbase = uni(((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * VPW);
+    if (jbase >= g.n) return;
+    Frozen<VEC> fz;
+    fz.bits = 0;
+    if constexpr (ES) { if (load_frozen<VEC>(done, tile, lane, fz)) return; }
+    unsigned tb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tb[q] = (q < n_levels) ? __float_as_uint(thr_next[q]) : 0x7fc00000u;
+#pragma unroll 1
+    for (int u = 0; u < VPW; ++u) {
+        const int j = jbase + u;
+        if (j >= g.n) break;
+        const int s0 = uni(g.var_ptr[j]);
+        const int dv = uni(g.var_ptr[j + 1]) - s0;
+        const float a = alpha_row[alpha_slot[j]];
+#define LDPC_VQ_CASE(D) \
+    case D: vn_q4_body<NL, ES, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut_s, beta_next, beta_slot, tb, bitsT, fz); break;
+        switch (dv) {
+            LDPC_VQ_CASE(0) LDPC_VQ_CASE(1) LDPC_VQ_CASE(2) LDPC_VQ_CASE(3) LDPC_VQ_CASE(4)
+            LDPC_VQ_CASE(5) LDPC_VQ_CASE(6) LDPC_VQ_CASE(7) LDPC_VQ_CASE(8)
+        default: break;
+        }
+#undef LDPC_VQ_CASE
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused RCQ iteration ("gather" form): ONE kernel per iteration, no V2C array at all.
 //
 // With 1-byte C2V codes the variable->check messages are cheaper to RECOMPUTE than to store: the check sweep of

@@ -140,7 +140,13 @@ class DecodeEngine:
         # same stream = serialised by the stream, different streams = different buffers.  Guarded by _ws_lock.
         self._ws = {}
         self._ws_lock = threading.Lock()
-        self.set_mode(os.environ.get("LDPC_ENGINE_MODE", "auto"))
+        mode = os.environ.get("LDPC_ENGINE_MODE", "auto")
+        try:
+            self.set_mode(mode)
+        except NotImplementedError:
+            if mode not in ("gather", "pair"):
+                raise
+            self.set_mode("stream")          # the RCQ-only forms, asked for process-wide: other decoders stream
 
     def __del__(self):
         try:
@@ -151,12 +157,15 @@ class DecodeEngine:
             pass
 
     # ------------------------------------------------------------------ engine choice
-    _MODES = {"auto": nat.MODE_AUTO, "stream": nat.MODE_STREAM, "resident": nat.MODE_RESIDENT, "sweeps": nat.MODE_SWEEPS}
+    _MODES = {"auto": nat.MODE_AUTO, "stream": nat.MODE_STREAM, "resident": nat.MODE_RESIDENT, "sweeps": nat.MODE_SWEEPS,
+              "gather": nat.MODE_GATHER, "pair": nat.MODE_PAIR}
 
     def set_mode(self, mode: str):
         """'auto' (LDS-resident fused kernel when the code qualifies, else streaming), 'stream' (HBM-streaming
-        engine; RCQ decoders run its fused one-kernel-per-iteration form), 'sweeps' (streaming, always one kernel
-        per sweep), 'resident' -- every choice gives identical results."""
+        engine; fp32 RCQ decoders run its cheapest applicable form: 1-byte codes both ways ('pair'), else the fused
+        one-kernel-per-iteration form ('gather')), 'sweeps' (streaming, always one kernel per sweep with fp32
+        variable->check rows), 'gather' / 'pair' (force that RCQ form; error when the decoder does not qualify),
+        'resident' -- every choice gives identical results."""
         nat.check(self._lib.ldpc_decoder_set_mode(self.handle, self._MODES[mode]), "ldpc_decoder_set_mode")
         with self._ws_lock:
             self._ws = {}
@@ -165,8 +174,8 @@ class DecodeEngine:
     def info(self) -> dict:
         out = np.zeros(4, dtype=np.int32)
         nat.check(self._lib.ldpc_decoder_info(self.handle, nat.ptr(out)), "ldpc_decoder_info")
-        return {"engine": {1: "stream", 2: "resident", 3: "stream"}[int(out[0])],
-                "stream_form": {1: "fused-rcq-iteration", 2: None, 3: "two-sweeps"}[int(out[0])],
+        return {"engine": {2: "resident", 3: "stream", 4: "stream", 5: "stream"}[int(out[0])],
+                "stream_form": {2: None, 3: "two-sweeps", 4: "fused-rcq-iteration", 5: "rcq-code-pair"}[int(out[0])],
                 "codewords_per_workgroup": int(out[1]),
                 "threads_per_workgroup": int(out[2]), "lds_bytes": int(out[3])}
 

@@ -109,16 +109,22 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
 
 /* Two engines implement the same arithmetic (bit-identical results):
  *   STREAM   : messages in HBM ([tile][edge][W]); any code, fp32/fp64.  One kernel per sweep (check sweep,
- *              variable sweep); fp32 RCQ decoders on graphs with variable degree <= 8 instead run ONE fused
- *              kernel per iteration that recomputes the variable->check messages from the 1-byte codes and the
- *              LLRs (no V2C array).  SWEEPS forces the two-sweep form for them too.
+ *              variable sweep).  fp32 flooding RCQ decoders have two cheaper forms, STREAM takes the first that applies:
+ *                PAIR   -- one beta per check, sorted thresholds, <= 62 levels: both message directions are 1-byte
+ *                          codes (the variable sweep quantises with the next iteration's beta and thresholds, the
+ *                          check sweep is integer-only): 4E + 4n bytes per codeword and iteration;
+ *                GATHER -- variable degree <= 8: ONE fused kernel per iteration that recomputes the variable->check
+ *                          messages from the 1-byte check->variable codes and the LLRs (no V2C array);
+ *              SWEEPS forces the plain two-sweep form (fp32 V2C rows); GATHER / PAIR force that form (error when the
+ *              decoder does not qualify).
  *   RESIDENT : one fused kernel, messages in LDS for all T iterations; fp32 codes with
- *              dc <= 32, dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code)
+ *              dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code)
  * AUTO (default) takes RESIDENT when the code qualifies, else STREAM. */
-enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2, LDPC_MODE_SWEEPS = 3 };
+enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2, LDPC_MODE_SWEEPS = 3, LDPC_MODE_GATHER = 4,
+       LDPC_MODE_PAIR = 5 };
 int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode);
-/* out4 = { engine a decode would use now (LDPC_MODE_RESIDENT, LDPC_MODE_STREAM = streaming with the fused RCQ
- * iteration, LDPC_MODE_SWEEPS = streaming with two sweeps per iteration), codewords per workgroup, threads per
+/* out4 = { engine and form a decode would use now (LDPC_MODE_RESIDENT, or the streaming form LDPC_MODE_PAIR /
+ * LDPC_MODE_GATHER / LDPC_MODE_SWEEPS), codewords per workgroup, threads per
  * workgroup, LDS bytes per workgroup } -- the last three 0 when the code does not qualify */
 int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4]);
 /* re-upload beta/alpha(/oms_alpha) tables of an existing decoder (same shapes);

@@ -25,7 +25,7 @@ def inference_mode():
         yield
 
 
-@pytest.fixture(autouse=True, params=["auto", "stream", "sweeps"])
+@pytest.fixture(autouse=True, params=["auto", "stream", "sweeps", "gather"])
 def engine_mode(request, monkeypatch):
     """'auto' = LDS-resident fused kernel where the code qualifies, 'stream' = HBM-streaming engine (RCQ: fused
     one-kernel-per-iteration form), 'sweeps' = streaming with one kernel per sweep"""

@@ -28,7 +28,7 @@ def inference_mode():
         yield
 
 
-@pytest.fixture(autouse=True, params=["auto", "stream", "sweeps"])
+@pytest.fixture(autouse=True, params=["auto", "stream", "sweeps", "gather"])
 def engine_mode(request, monkeypatch):
     """every test runs on every engine form: 'auto' picks the LDS-resident fused kernel for codes that qualify
     (all the fp32 fixtures here), 'stream' the HBM-streaming engine (RCQ decoders: its fused one-kernel-per-
@@ -479,6 +479,51 @@ def test_odd_degrees_and_iteration_counts(T, gpu_device, oracle_mod):
     np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
 
 
+@pytest.mark.parametrize("bc,B", [(3, 300), (3, 40), (4, 300), (5, 130), (5, 7)])
+@pytest.mark.parametrize("early_stop", [True, False])
+def test_rcq_code_pair_form_edge_cases(bc, B, early_stop, gpu_device, oracle_mod, engine_mode):
+    """The streaming form that sends BOTH directions as 1-byte codes (vn_sweep_q / cn_sweep_q: the variable side applies
+    the next iteration's beta and quantiser) against the CPU restatement and against the fp32-V2C sweeps, on inputs that
+    hit its special cases: negative and zero betas (sign of beta * min, all-zero magnitudes), exact-zero and tied
+    messages, 4 / 8 / 16 levels (compile-time compare chain, register thresholds, threshold loop), 256- and
+    64-codeword tiles, odd degrees (dc > 32, dv > 8) next to the (96,48) code."""
+    if engine_mode != "stream":
+        pytest.skip("sets the engine forms itself")
+    import codes
+    from rcq_decoder import WeightedRCQDecoder
+    rng = np.random.default_rng(100 * bc + B)
+    qp = QP if bc == 3 else [(4.0, 1.2), (6.0, 1.0), (9.0, 0.8)]
+    for code, T in ((codes.load_code("small_96_48", 10), 7), (odd_code(), 5)):
+        og = oracle_mod.OracleGraph(code.H)
+        llr = (rng.standard_normal((B, code.n)) * 2.5 + 1.0).astype(np.float32)
+        llr[0] = np.round(llr[0])                                    # ties and exact zeros
+        llr[1 % B, ::3] = 0.0
+        x = torch.from_numpy(llr).to(gpu_device)
+        dec = WeightedRCQDecoder(code, bc, 8, qp, weight_sharing_type=2, max_iterations=T)
+        with torch.no_grad():
+            for i, p_ in enumerate(dec.beta_weights.values()):
+                p_.fill_(float(np.float32([0.8, -0.6, 0.0, 1.3][i % 4] if i % 5 else rng.uniform(0.4, 1.1))))
+            for p_ in dec.alpha_weights.values():
+                p_.fill_(float(np.float32(rng.uniform(0.7, 1.2))))
+        beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+        alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+        eng = dec._get_engine(gpu_device)
+        eng.set_mode("pair")
+        assert eng.info()["stream_form"] == "rcq-code-pair"
+        a = eng.decode(x, early_stop=early_stop)
+        ca = eng.debug_c2v(B).cpu().numpy()
+        eng.set_mode("sweeps")
+        b = eng.decode(x, early_stop=early_stop)
+        cb = eng.debug_c2v(B).cpu().numpy()
+        ob, op, oi, osucc = oracle_mod.weighted_rcq(og, llr, bc, qp, 2, T, beta, alpha, early_stop=early_stop)
+        np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+        np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+        np.testing.assert_array_equal(a.success.cpu().numpy(), osucc)
+        np.testing.assert_array_equal(a.posterior.cpu().numpy(), op)
+        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.bits, b.bits)
+        np.testing.assert_array_equal(ca, cb)                        # per-edge codes of the last executed iteration
+
+
 def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
     """RCQMinSumDecoder(layered=True): the reference's own outputs (toy, 48x96), then fresh batches on the
     (1998,1512) code against the oracle in both stop modes"""
@@ -911,8 +956,12 @@ def test_random_graphs_engines_agree_with_the_oracle(seed, gpu_device, oracle_mo
         eng.set_mode("auto")
         assert eng.info()["engine"] == "resident"
         a = eng.decode(inp, early_stop=early, want_packed=True)
-        for mode in ("stream", "sweeps"):
-            eng.set_mode(mode)
+        for mode in ("stream", "sweeps", "gather", "pair"):
+            try:
+                eng.set_mode(mode)
+            except NotImplementedError:
+                assert mode in ("gather", "pair")               # the RCQ-only forms
+                continue
             b = eng.decode(inp, early_stop=early, want_packed=True)
             assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
             assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)

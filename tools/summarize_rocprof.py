@@ -65,7 +65,7 @@ def main():
             # cn_sweep<T, VEC, FORM, FIRST, ...> has FIRST as its 4th argument)
             best = None
             for k, v in traffic.items():
-                if not k.startswith("ldpc::" + prefix):
+                if k.split("<")[0] != "ldpc::" + prefix:
                     continue
                 args = k[k.index("<") + 1:k.rindex(">")].split(", ") if "<" in k else []
                 if prefix == "cn_sweep" and len(args) >= 4 and args[3] != "false":
@@ -76,7 +76,7 @@ def main():
                     best = v
             return best
 
-        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather"):
+        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather", "cn_sweep_q4", "vn_sweep_q4"):
             v = pick(key)
             if v is not None:
                 entry[key] = {"bytes_per_launch": v, "source": src}
