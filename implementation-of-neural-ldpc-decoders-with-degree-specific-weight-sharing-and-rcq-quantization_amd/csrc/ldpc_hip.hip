@@ -323,16 +323,24 @@ int launch_cn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done
     return LDPC_OK;
 }
 
-// code-pair form, iterations < T-1: C2V codes of iteration `it` (w.c2v) -> V2C codes for iteration it + 1 (w.v2c)
+// 256-codeword tiles of a decoder whose variable sweep can run vn_sweep_q4 (degrees <= 8, at most 8 levels)
+template <int VEC>
+bool pair_q4(const ldpc_decoder *d) { return VEC == 4 && d->g->max_dv <= 8 && d->n_levels <= 8; }
+
+// code-pair form, iterations < T-1: C2V codes of iteration `it` (w.c2v) -> V2C codes for iteration it + 1 (w.v2c).
+// it == -1 (pair_q4 decoders only): the pass before iteration 0, LLRs -> V2C codes for iteration 0.
 template <int VEC>
 int launch_vn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
 {
+    const bool init = it < 0;
+    if (init) it = 0;
     const GraphDev g = d->g->dev();
     const int vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid((unsigned)((size_t)w.tiles * vb)), block(kBlock);
     const float *alpha_row = (const float *)d->alpha + (size_t)it * d->n_alpha;
-    const float *beta_next = (const float *)d->beta + (size_t)(it + 1) * d->n_beta;
-    const float *thr_next = d->thresholds + (size_t)d->q_of_iter[it + 1] * d->n_levels;
+    const int nxt = init ? 0 : it + 1;
+    const float *beta_next = (const float *)d->beta + (size_t)nxt * d->n_beta;
+    const float *thr_next = d->thresholds + (size_t)d->q_of_iter[nxt] * d->n_levels;
     const int lut_entries = 2 * d->n_levels;
     const float *lut_cur = d->lut + (size_t)d->q_of_iter[it] * lut_entries;
     const size_t shmem = (size_t)lut_entries * sizeof(float);
@@ -347,7 +355,15 @@ int launch_vn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done
     hipLaunchKernelGGL((vn_sweep_q4<NL_, ES_, LDPC_VNQ_VPW>), grid4, block, shmem, s, g, (const uint8_t *)w.c2v,         \
                        (const float *)w.llrT, (uint8_t *)w.v2c, alpha_row, (const int *)d->alpha_slot, lut_cur,         \
                        lut_entries, beta_next, (const int *)d->beta_slot, thr_next, d->n_levels, w.bitsT, done, vb4)
-    if (VEC == 4 && d->g->max_dv <= 8 && d->n_levels <= 8) {
+    if (init) {
+        if (!pair_q4<VEC>(d)) return fail(LDPC_ERR_ARG, "internal: code-pair initial pass on a decoder without vn_sweep_q4");
+#define LDPC_VQI(NL_)                                                                                                 \
+    hipLaunchKernelGGL((vn_sweep_q4<NL_, false, LDPC_VNQ_VPW, true>), grid4, block, 0, s, g, (const uint8_t *)w.c2v,     \
+                       (const float *)w.llrT, (uint8_t *)w.v2c, alpha_row, (const int *)d->alpha_slot, lut_cur,         \
+                       lut_entries, beta_next, (const int *)d->beta_slot, thr_next, d->n_levels, w.bitsT, done, vb4)
+        if (d->n_levels == 4) LDPC_VQI(4); else LDPC_VQI(0);
+#undef LDPC_VQI
+    } else if (pair_q4<VEC>(d)) {
         if (d->n_levels == 4) { if (done) LDPC_VQ4(4, true); else LDPC_VQ4(4, false); }
         else { if (done) LDPC_VQ4(0, true); else LDPC_VQ4(0, false); }
     }
@@ -481,11 +497,16 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     }
     if (use_pair(d) && !saved) {
         if constexpr (sizeof(T) == 4) {
-            // RCQ, code-pair form: iteration 0 is the plain check sweep on the LLRs; after that both directions are
-            // 1-byte codes (vn_sweep_q quantises with the next iteration's beta and thresholds, cn_sweep_q is integer-only);
+            // RCQ, code-pair form: both directions are 1-byte codes (iteration 0 of decoders without vn_sweep_q4 is the plain
+            // check sweep on the LLRs) (vn_sweep_q quantises with the next iteration's beta and thresholds, cn_sweep_q is integer-only);
             // the last variable pass is the ordinary posterior pass over the C2V codes.
+            const bool q4 = pair_q4<VEC>(d);      // LLRs -> V2C codes first, then iteration 0 is a code sweep like the others
+            if (q4 && T_it > 0) {
+                int rc = launch_vn_q<VEC>(d, w, -1, false, s);
+                if (rc) return rc;
+            }
             for (int it = 0; it < T_it; ++it) {
-                int rc = it == 0 ? launch_cn<T, VEC>(d, w, 0, early_stop, s) : launch_cn_q<VEC>(d, w, it, early_stop, s);
+                int rc = (it == 0 && !q4) ? launch_cn<T, VEC>(d, w, 0, early_stop, s) : launch_cn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
                 rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s)
                                     : launch_vn_q<VEC>(d, w, it, early_stop, s);
@@ -1522,7 +1543,8 @@ int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_
     if (use_pair(d) && !f64) {
         // code-pair form: which = 0 the check sweep (integer-only from iteration 1), which = 1 the variable sweep
         // (code-producing except in the last iteration)
-        if (which == 0 && iter >= 1) return w.vec == 1 ? launch_cn_q<1>(d, w, iter, false, s) : launch_cn_q<4>(d, w, iter, false, s);
+        if (which == 0 && (iter >= 1 || (w.vec == 4 && pair_q4<4>(d))))
+            return w.vec == 1 ? launch_cn_q<1>(d, w, iter, false, s) : launch_cn_q<4>(d, w, iter, false, s);
         if (which != 0 && iter < d->T - 1) return w.vec == 1 ? launch_vn_q<1>(d, w, iter, false, s) : launch_vn_q<4>(d, w, iter, false, s);
     }
     if (use_gather(d) && !f64) {

@@ -1205,7 +1205,9 @@ __device__ __forceinline__ float lut_at(unsigned byte_off)
     return *(__attribute__((address_space(3))) const float *)(size_t)byte_off;
 }
 
-template <int NL, bool ES, int DV>
+// INIT: the pass before iteration 0 -- every outgoing message is the LLR itself ("initialize with channel LLRs",
+// rcq_decoder.py:514-518), coded with iteration 0's beta and thresholds; no codes are read.
+template <int NL, bool ES, bool INIT, int DV>
 __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int s0, int lane,
                                            const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
                                            uint8_t *__restrict__ v2c, float a, const float *lut_s,
@@ -1222,7 +1224,8 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
 #pragma unroll
     for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
 #pragma unroll
-    for (int k = 0; k < DV; ++k) q[k] = __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(c2v + (tileE + e[k]) * W + lane_off)) << 2;
+    for (int k = 0; k < DV; ++k)
+        q[k] = INIT ? 0u : __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(c2v + (tileE + e[k]) * W + lane_off)) << 2;
     const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
 #pragma unroll
     for (int k = 0; k < DV; ++k) bb[k] = beta_next[beta_slot[e[k]]];
@@ -1233,13 +1236,15 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                 // codewords 2h, 2h + 1 as one float pair (v_pk_add/mul_f32)
         f32x2 xs[D];
+        if constexpr (!INIT) {
 #pragma unroll
-        for (int k = 0; k < DV; ++k) {            // codes < 16 here: (code << 2) is the byte offset into the LUT
-            xs[k].x = lut_at((q[k] >> (16 * h)) & 0xffu);
-            xs[k].y = lut_at((q[k] >> (16 * h + 8)) & 0xffu);
+            for (int k = 0; k < DV; ++k) {        // codes < 16 here: (code << 2) is the byte offset into the LUT
+                xs[k].x = lut_at((q[k] >> (16 * h)) & 0xffu);
+                xs[k].y = lut_at((q[k] >> (16 * h + 8)) & 0xffu);
+            }
         }
         const f32x2 lh = {l.x[2 * h], l.x[2 * h + 1]};
-        if constexpr (ES) {
+        if constexpr (ES && !INIT) {
             const f32x2 post = lh + sum_ct<DV, -1, 0, f32x2>(xs);
             const uint64_t b0 = __ballot(post.x < 0.0f), b1 = __ballot(post.y < 0.0f);
             if (lane == 0) {
@@ -1248,6 +1253,10 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
             }
         }
         f32x2 v[D];
+        if constexpr (INIT) {
+#pragma unroll
+            for (int k = 0; k < DV; ++k) v[k] = lh;
+        } else {
         if constexpr (DV >= 1) v[0] = lh + a * sum_ct<DV - 1, 0, 0, f32x2>(xs);
         if constexpr (DV >= 2) v[1] = lh + a * sum_ct<DV - 1, 1, 0, f32x2>(xs);
         if constexpr (DV >= 3) v[2] = lh + a * sum_ct<DV - 1, 2, 0, f32x2>(xs);
@@ -1256,6 +1265,7 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
         if constexpr (DV >= 6) v[5] = lh + a * sum_ct<DV - 1, 5, 0, f32x2>(xs);
         if constexpr (DV >= 7) v[6] = lh + a * sum_ct<DV - 1, 6, 0, f32x2>(xs);
         if constexpr (DV >= 8) v[7] = lh + a * sum_ct<DV - 1, 7, 0, f32x2>(xs);
+        }
 #pragma unroll
         for (int k = 0; k < DV; ++k) {
             const unsigned k0 = key_of<NL>(v[k].x, bb[k], tb), k1 = key_of<NL>(v[k].y, bb[k], tb);
@@ -1281,7 +1291,7 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
 #ifndef LDPC_VNQ_VPW
 #define LDPC_VNQ_VPW 8
 #endif
-template <int NL, bool ES, int VPW>
+template <int NL, bool ES, int VPW, bool INIT = false>
 __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t *__restrict__ c2v,
                                                       const float *__restrict__ llrT, uint8_t *__restrict__ v2c,
                                                       const float *__restrict__ alpha_row, const int *__restrict__ alpha_slot,
@@ -1294,8 +1304,10 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
     constexpr int VEC = 4;
     extern __shared__ float lut_s[];
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();      // lut_at relies on that (folds away)
-    for (int k = threadIdx.x; k < lut_entries; k += kBlock) lut_s[k] = lut_cur[k];
-    __syncthreads();
+    if constexpr (!INIT) {
+        for (int k = threadIdx.x; k < lut_entries; k += kBlock) lut_s[k] = lut_cur[k];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int tile = uni(blockIdx.x / var_blocks);
     const int jbase = uni(((blockIdx.x % var_blocks) * kWavesPerBlock + (threadIdx.x >> 6)) * VPW);
@@ -1312,9 +1324,9 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
         if (j >= g.n) break;
         const int s0 = uni(g.var_ptr[j]);
         const int dv = uni(g.var_ptr[j + 1]) - s0;
-        const float a = alpha_row[alpha_slot[j]];
+        const float a = INIT ? 0.0f : alpha_row[alpha_slot[j]];
 #define LDPC_VQ_CASE(D) \
-    case D: vn_q4_body<NL, ES, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut_s, beta_next, beta_slot, tb, bitsT, fz); break;
+    case D: vn_q4_body<NL, ES, INIT, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut_s, beta_next, beta_slot, tb, bitsT, fz); break;
         switch (dv) {
             LDPC_VQ_CASE(0) LDPC_VQ_CASE(1) LDPC_VQ_CASE(2) LDPC_VQ_CASE(3) LDPC_VQ_CASE(4)
             LDPC_VQ_CASE(5) LDPC_VQ_CASE(6) LDPC_VQ_CASE(7) LDPC_VQ_CASE(8)

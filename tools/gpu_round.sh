@@ -7,7 +7,7 @@
 set -o pipefail
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/$TAG; mkdir -p $O
+O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo "default bench failed" >> $O/errors.log
 for w in neural2d rcq wrcq_dvbs2 basic_f64; do
   timeout -k 10 300 python bench.py --workload $w --steps 10 --warmup 3 > $O/bench_$w.json 2> $O/bench_$w.err || echo "bench $w failed" >> $O/errors.log
