@@ -445,12 +445,13 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                 const Workspace &w, hipStream_t s, char *saved = nullptr)
 {
     constexpr int W = 64 * VEC;
-    constexpr int JT = 128 / sizeof(T);
+    constexpr int JT = transpose_vars<T>();
     const GraphDev g = d->g->dev();
     const int T_it = d->T;
     const int vc = (g.n + JT - 1) / JT;
+    const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc));       // transposes: one block per (tile, 64-codeword run, chunk)
 
-    hipLaunchKernelGGL((transpose_in<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((transpose_in<T, VEC>), tgrid, dim3(kBlock), 0, s,
                        (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
     {
         const long long cnt = (long long)w.tiles * W;
@@ -474,7 +475,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
             HIP_TRY(hipGetLastError());
             if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
             if (bits || posterior)
-                hipLaunchKernelGGL((transpose_out<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+                hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
                                    (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
             if (iterations || success || packed) {
                 long long threads = batch;
@@ -577,7 +578,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     HIP_TRY(hipGetLastError());
 
     if (bits || posterior) {
-        hipLaunchKernelGGL((transpose_out<T, VEC>), dim3((unsigned)((size_t)w.tiles * vc)), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
                            (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
     }
     if (iterations || success || packed) {
@@ -1378,11 +1379,11 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
                   float *grad_llr, const BackwardWs &w, hipStream_t s)
 {
     constexpr int W = 64 * VEC;
-    constexpr int JT = 32;
+    constexpr int JT = transpose_vars<float>();
     const GraphDev g = d->g->dev();
     const int T = d->T, vc = (g.n + JT - 1) / JT;
     const SavedLayout sl = saved_layout(d, w.tiles, W);
-    const dim3 tgrid((unsigned)((size_t)w.tiles * vc)), blk(kBlock);
+    const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc)), blk(kBlock);
     hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, llr, w.llrT, (long long)batch, g.n, vc);
     hipLaunchKernelGGL((transpose_in<float, VEC>), tgrid, blk, 0, s, grad_posterior, w.gpostT, (long long)batch, g.n, vc);
     HIP_TRY(hipMemsetAsync(w.gbeta, 0, w.part_bytes, s));
@@ -1418,7 +1419,8 @@ int backward_impl(const ldpc_decoder *d, const char *saved, const float *llr, in
     }
     HIP_TRY(hipGetLastError());
     if (grad_llr)
-        hipLaunchKernelGGL((untranspose_rows<VEC>), tgrid, blk, 0, s, (const float *)w.gllrT, grad_llr, (long long)batch, g.n, vc);
+        hipLaunchKernelGGL((transpose_out<float, VEC>), tgrid, blk, 0, s, (const float *)w.gllrT, (const uint64_t *)nullptr, grad_llr,
+                           (int *)nullptr, (long long)batch, g.n, vc);     // [tile][n][W] -> [batch][n], padding rows dropped
     // fixed-order reductions (one wave per slot and iteration): every table entry is written, no memset, no atomics
     if (grad_beta)
         hipLaunchKernelGGL(reduce_table_grads, dim3((unsigned)d->n_beta, (unsigned)T), dim3(kWave), 0, s,

@@ -1885,26 +1885,33 @@ __global__ void init_state(uint64_t *__restrict__ done, int *__restrict__ iters,
 // ------------------------------------------------------------------------------------------
 // Layout changes at the API edge: llr[B][n] -> llrT[tile][n][W]; posterior / bits back.
 // ------------------------------------------------------------------------------------------
+// Layout changes at the boundary: caller rows [B][n] <-> workspace tiles [tile][n][W].  One block moves 64 codewords x
+// kTransposeBytes / sizeof(T) variables through LDS, so that BOTH sides are touched in runs of at least 256 contiguous
+// bytes (a wave reads 256 B of one codeword's row and writes the 64-codeword run of one variable's tile row) -- with
+// 32-variable blocks the caller side was touched 128 B at a time and the two kernels ran at 2.5-2.7 TB/s.
+constexpr int kTransposeBytes = 512;
+template <typename T> constexpr int transpose_vars() { return kTransposeBytes / (int)sizeof(T); }
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void transpose_in(const T *__restrict__ llr, T *__restrict__ llrT,
                                                        long long batch, int n, int var_chunks)
 {
     constexpr int W = kWave * VEC;
-    constexpr int JT = 128 / sizeof(T);
-    __shared__ T s[JT][W + 1];
-    const int tile = blockIdx.x / var_chunks;
-    const int j0 = (blockIdx.x % var_chunks) * JT;
-    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+    constexpr int JT = transpose_vars<T>();
+    __shared__ T s[JT][kWave + 1];
+    const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
+    const int j0 = chunk * JT, w0 = sub * kWave;
+    for (int idx = threadIdx.x; idx < kWave * JT; idx += kBlock) {
         const int r = idx / JT, jj = idx % JT;
-        const long long b = (long long)tile * W + r;
+        const long long b = (long long)tile * W + w0 + r;
         T v = (T)1;                                     // padding codewords: benign positive LLR
         if (b < batch && j0 + jj < n) v = llr[(size_t)b * n + j0 + jj];
         s[jj][r] = v;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
-        const int jj = idx / W, w = idx % W;
-        if (j0 + jj < n) llrT[((size_t)tile * n + j0 + jj) * W + w] = s[jj][w];
+    for (int idx = threadIdx.x; idx < kWave * JT; idx += kBlock) {
+        const int jj = idx / kWave, w = idx % kWave;
+        if (j0 + jj < n) llrT[((size_t)tile * n + j0 + jj) * W + w0 + w] = s[jj][w];
     }
 }
 
@@ -1915,15 +1922,15 @@ __global__ __launch_bounds__(kBlock) void transpose_out(const T *__restrict__ po
                                                         long long batch, int n, int var_chunks)
 {
     constexpr int W = kWave * VEC;
-    constexpr int JT = 128 / sizeof(T);
-    __shared__ T s[JT][W + 1];
+    constexpr int JT = transpose_vars<T>();
+    __shared__ T s[JT][kWave + 1];
     __shared__ uint64_t sb[JT][VEC];
-    const int tile = blockIdx.x / var_chunks;
-    const int j0 = (blockIdx.x % var_chunks) * JT;
+    const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
+    const int j0 = chunk * JT, w0 = sub * kWave;
     if (posterior) {
-        for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
-            const int jj = idx / W, w = idx % W;
-            if (j0 + jj < n) s[jj][w] = postT[((size_t)tile * n + j0 + jj) * W + w];
+        for (int idx = threadIdx.x; idx < kWave * JT; idx += kBlock) {
+            const int jj = idx / kWave, w = idx % kWave;
+            if (j0 + jj < n) s[jj][w] = postT[((size_t)tile * n + j0 + jj) * W + w0 + w];
         }
     }
     if (bits) {
@@ -1933,12 +1940,13 @@ __global__ __launch_bounds__(kBlock) void transpose_out(const T *__restrict__ po
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
+    for (int idx = threadIdx.x; idx < kWave * JT; idx += kBlock) {
         const int r = idx / JT, jj = idx % JT;
-        const long long b = (long long)tile * W + r;
+        const int rw = w0 + r;                          // codeword inside the tile: lane rw / VEC, slot rw % VEC
+        const long long b = (long long)tile * W + rw;
         if (b < batch && j0 + jj < n) {
             if (posterior) posterior[(size_t)b * n + j0 + jj] = s[jj][r];
-            if (bits) bits[(size_t)b * n + j0 + jj] = (int)((sb[jj][r % VEC] >> (r / VEC)) & 1ull);
+            if (bits) bits[(size_t)b * n + j0 + jj] = (int)((sb[jj][rw % VEC] >> (rw / VEC)) & 1ull);
         }
     }
 }

@@ -344,28 +344,6 @@ __global__ __launch_bounds__(kBlock) void llr_backward_accumulate(GraphDev g, co
     st<float, VEC>(acc_row, acc);
 }
 
-// [tile][n][W] -> [batch][n] (rows of padding codewords are dropped)
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void untranspose_rows(const float *__restrict__ srcT, float *__restrict__ dst,
-                                                           long long batch, int n, int var_chunks)
-{
-    constexpr int W = kWave * VEC;
-    constexpr int JT = 32;
-    __shared__ float s[JT][W + 1];
-    const int tile = blockIdx.x / var_chunks;
-    const int j0 = (blockIdx.x % var_chunks) * JT;
-    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
-        const int jj = idx / W, w = idx % W;
-        if (j0 + jj < n) s[jj][w] = srcT[((size_t)tile * n + j0 + jj) * W + w];
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < W * JT; idx += kBlock) {
-        const int r = idx / JT, jj = idx % JT;
-        const long long b = (long long)tile * W + r;
-        if (b < batch && j0 + jj < n) dst[(size_t)b * n + j0 + jj] = s[jj][r];
-    }
-}
-
 // grad_table[t][s] = sum over the items x of slot s (x = edge for beta, variable for alpha) and over the tiles of
 // part[t][tile][x].  One wave per (slot, iteration), grid = (n_slots, T): lane l takes the items l, l+64, ... of the
 // slot's list (built by the host: slot_ptr / slot_items, the inverse of the slot map) in that order, sums in double,
