@@ -194,7 +194,8 @@ def load_traffic(workload):
     tools/summarize_rocprof.py with the gfx950 correction); every number carries the file it came from"""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tf)).get(workload, {})
+        db = json.load(open(tf))
+        return {**db.get(workload + "_gather", {}), **db.get(workload, {})}     # `_gather`: the pass with that RCQ form forced
     except Exception:
         return {}
 

@@ -23,6 +23,12 @@ for w in basic neural2d rcq wrcq_dvbs2; do
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_$w -- python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-legs --sweep-reps 3 > $O/write_$w.log 2>&1 || echo "write $w failed" >> $O/errors.log
   echo "profiled $w"
 done
+# the fused gather form of config 5 (the code-pair form is the default there): same three passes with the form forced
+export LDPC_ENGINE_MODE=gather
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wrcq_dvbs2_gather -- python3 bench.py --workload wrcq_dvbs2 --steps 5 --warmup 2 --no-cpu-baseline --no-legs > $O/stats_wrcq_dvbs2_gather.log 2>&1 || echo "stats gather failed" >> $O/errors.log
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch_wrcq_dvbs2_gather -- python3 bench.py --workload wrcq_dvbs2 --steps 2 --warmup 1 --no-cpu-baseline --no-legs --sweep-reps 3 > $O/fetch_wrcq_dvbs2_gather.log 2>&1 || echo "fetch gather failed" >> $O/errors.log
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write_wrcq_dvbs2_gather -- python3 bench.py --workload wrcq_dvbs2 --steps 2 --warmup 1 --no-cpu-baseline --no-legs --sweep-reps 3 > $O/write_wrcq_dvbs2_gather.log 2>&1 || echo "write gather failed" >> $O/errors.log
+unset LDPC_ENGINE_MODE
 # SQ / LDS counters of the two dominant kernels (three passes each)
 N=1
 pass() { local w=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/ctr_${w}_p$N -- python3 tools/time_sweeps.py --workload $w > $O/ctr_${w}_p$N.log 2>&1 || echo "counter pass $w $N failed" >> $O/errors.log; N=$((N+1)); }

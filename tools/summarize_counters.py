@@ -3,7 +3,7 @@
 SQ / LDS counters of one kernel plus a few derived ratios.
 
     python tools/summarize_counters.py <tag> <workload> <kernel substring> <name>
-    e.g. r02 basic resident_decode resident   |   r02 wrcq_dvbs2 cn_gather gather"""
+    e.g. r02 basic resident_decode resident   |   r02 wrcq_dvbs2 vn_sweep_q4 pair_vn"""
 import collections, csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, workload, kernel, name = sys.argv[1:5]
@@ -18,7 +18,7 @@ if "SQ_WAVE_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
     d["derived_valu_active_per_wave_cycle"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_WAVE_CYCLES"]
 if "SQ_BUSY_CYCLES" in avg and "SQ_ACTIVE_INST_VALU" in avg:
     d["derived_valu_active_per_busy_cycle"] = avg["SQ_ACTIVE_INST_VALU"] / avg["SQ_BUSY_CYCLES"]
-if "SQ_LDS_IDX_ACTIVE" in avg and "SQ_LDS_BANK_CONFLICT" in avg:
+if avg.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in avg:
     d["derived_lds_conflict_share_of_lds_cycles"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]
 if "SQ_WAIT_ANY" in avg and "SQ_WAVE_CYCLES" in avg:
     d["derived_wait_share_of_wave_cycles"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
