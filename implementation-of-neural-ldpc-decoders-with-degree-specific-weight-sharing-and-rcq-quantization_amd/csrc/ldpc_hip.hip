@@ -451,8 +451,14 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     const int vc = (g.n + JT - 1) / JT;
     const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc));       // transposes: one block per (tile, 64-codeword run, chunk)
 
-    hipLaunchKernelGGL((transpose_in<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                       (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+    // 16-byte vector forms of the layout changes when rows and buffers allow
+    auto vec_ok = [&](const void *a, const void *b) {
+        return g.n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)a & 15u) == 0 && ((uintptr_t)b & 15u) == 0;
+    };
+    if (vec_ok(llr, nullptr))
+        hipLaunchKernelGGL((transpose_in_v<T, VEC>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+    else
+        hipLaunchKernelGGL((transpose_in<T, VEC>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
     {
         const long long cnt = (long long)w.tiles * W;
         hipLaunchKernelGGL((init_state<VEC>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, w.done,
@@ -474,9 +480,14 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                                    d->g->max_dc, (uint8_t *)nullptr);
             HIP_TRY(hipGetLastError());
             if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
-            if (bits || posterior)
-                hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                                   (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+            if (bits || posterior) {
+                if (vec_ok(posterior, bits))
+                    hipLaunchKernelGGL((transpose_out_v<T, VEC>), tgrid, dim3(kBlock), 0, s,
+                                       (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+                else
+                    hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
+                                       (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+            }
             if (iterations || success || packed) {
                 long long threads = batch;
                 if (packed) threads = std::max<long long>(threads, std::min<long long>(batch * ((g.n + 7) / 8), 1ll << 22));
@@ -578,8 +589,12 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     HIP_TRY(hipGetLastError());
 
     if (bits || posterior) {
-        hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                           (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+        if (vec_ok(posterior, bits))
+            hipLaunchKernelGGL((transpose_out_v<T, VEC>), tgrid, dim3(kBlock), 0, s,
+                               (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+        else
+            hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
+                               (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
     }
     if (iterations || success || packed) {
         long long threads = batch;

@@ -1951,6 +1951,124 @@ __global__ __launch_bounds__(kBlock) void transpose_out(const T *__restrict__ po
     }
 }
 
+// 16-byte-per-lane versions of the two layout changes (n a multiple of 16 / sizeof(T), 16-byte aligned caller buffers):
+// every thread issues its eight vector loads before the first use, so that a block keeps 32 KB in flight -- the scalar
+// kernels above have one or two 256-byte requests in flight per wave and run at half the sweep rate.
+template <typename T> struct Vec16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void transpose_in_v(const T *__restrict__ llr, T *__restrict__ llrT,
+                                                         long long batch, int n, int var_chunks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int JT = transpose_vars<T>();
+    constexpr int VT = 16 / (int)sizeof(T);            // elements per 16-byte vector
+    constexpr int CV = JT / VT;                        // vectors per codeword run (32)
+    constexpr int WV = kWave / VT;                     // vectors per variable run
+    constexpr int PER = kWave * CV / kBlock;           // vectors per thread (8)
+    using V = typename Vec16<T>::type;
+    __shared__ T s[JT][kWave + 1];
+    const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
+    const int j0 = chunk * JT, w0 = sub * kWave;
+    V v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + k * kBlock, r = idx / CV, c = idx % CV;
+        const long long b = (long long)tile * W + w0 + r;
+        v[k] = (T)1;                                    // padding codewords: benign positive LLR
+        if (b < batch && j0 + c * VT < n) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(llr + (size_t)b * n + j0 + c * VT));
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + k * kBlock, r = idx / CV, c = idx % CV;
+#pragma unroll
+        for (int q = 0; q < VT; ++q) s[c * VT + q][r] = v[k][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < JT * WV / kBlock; ++k) {
+        const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
+        V o;
+#pragma unroll
+        for (int q = 0; q < VT; ++q) o[q] = s[jj][wv * VT + q];
+        if (j0 + jj < n) *reinterpret_cast<V *>(llrT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * VT) = o;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void transpose_out_v(const T *__restrict__ postT,
+                                                          const uint64_t *__restrict__ bitsT,
+                                                          T *__restrict__ posterior, int *__restrict__ bits,
+                                                          long long batch, int n, int var_chunks)
+{
+    constexpr int W = kWave * VEC;
+    constexpr int JT = transpose_vars<T>();
+    constexpr int VT = 16 / (int)sizeof(T);
+    constexpr int CV = JT / VT;
+    constexpr int WV = kWave / VT;
+    constexpr int PER = JT * WV / kBlock;
+    constexpr int PB = kWave + 4;                      // byte row of the expanded hard decisions (rows stay 4-byte aligned)
+    using V = typename Vec16<T>::type;
+    typedef int IV __attribute__((ext_vector_type(VT)));
+    typedef uint8_t BV __attribute__((ext_vector_type(VT)));
+    __shared__ T s[JT][kWave + 1];
+    __shared__ __align__(4) uint8_t pb[JT][PB];        // hard decision of (variable, codeword of this run), one byte each
+    const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
+    const int j0 = chunk * JT, w0 = sub * kWave;
+    if (posterior) {
+        V v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
+            v[k] = (T)0;
+            if (j0 + jj < n) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(postT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * VT));
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
+#pragma unroll
+            for (int q = 0; q < VT; ++q) s[jj][wv * VT + q] = v[k][q];
+        }
+    }
+    if (bits) {
+        // ballot words -> one byte per (variable, codeword): the thread that owns VT consecutive codewords of a variable
+        // reads the (at most VT) words holding them -- the 64 / VT threads of a variable read the same words, one request
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
+            BV o;
+#pragma unroll
+            for (int q = 0; q < VT; ++q) {
+                const int rw = w0 + wv * VT + q;        // codeword inside the tile: ballot lane rw / VEC, word rw % VEC
+                const uint64_t word = (j0 + jj < n) ? bitsT[((size_t)tile * n + j0 + jj) * VEC + (rw % VEC)] : 0ull;
+                const unsigned half = (rw / VEC) < 32 ? (unsigned)word : (unsigned)(word >> 32);
+                o[q] = (uint8_t)((half >> ((rw / VEC) & 31)) & 1u);
+            }
+            *reinterpret_cast<BV *>(&pb[jj][wv * VT]) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWave * CV / kBlock; ++k) {
+        const int idx = threadIdx.x + k * kBlock, r = idx / CV, c = idx % CV;
+        const long long b = (long long)tile * W + w0 + r;
+        if (b < batch && j0 + c * VT < n) {
+            if (posterior) {
+                V o;
+#pragma unroll
+                for (int q = 0; q < VT; ++q) o[q] = s[c * VT + q][r];
+                __builtin_nontemporal_store(o, reinterpret_cast<V *>(posterior + (size_t)b * n + j0 + c * VT));
+            }
+            if (bits) {
+                IV o;
+#pragma unroll
+                for (int q = 0; q < VT; ++q) o[q] = (int)pb[c * VT + q][r];
+                __builtin_nontemporal_store(o, reinterpret_cast<IV *>(bits + (size_t)b * n + j0 + c * VT));
+            }
+        }
+    }
+}
+
 // iterations / success / packed hard decisions, one thread per (codeword, output byte)
 template <int VEC>
 __global__ void finalize_out(const uint64_t *__restrict__ done, const int *__restrict__ iters_ws,
