@@ -498,6 +498,9 @@ def test_rcq_code_pair_form_edge_cases(bc, B, early_stop, gpu_device, oracle_mod
         llr = (rng.standard_normal((B, code.n)) * 2.5 + 1.0).astype(np.float32)
         llr[0] = np.round(llr[0])                                    # ties and exact zeros
         llr[1 % B, ::3] = 0.0
+        if B > 3:                                                    # saturated inputs: |beta * inf| = inf, 0 * inf = NaN -> code 0
+            llr[2, ::5] = np.inf
+            llr[3, 1::4] = -np.inf
         x = torch.from_numpy(llr).to(gpu_device)
         dec = WeightedRCQDecoder(code, bc, 8, qp, weight_sharing_type=2, max_iterations=T)
         with torch.no_grad():
