@@ -1208,10 +1208,9 @@ __device__ __forceinline__ float lut_at(unsigned byte_off)
 // INIT: the pass before iteration 0 -- every outgoing message is the LLR itself ("initialize with channel LLRs",
 // rcq_decoder.py:514-518), coded with iteration 0's beta and thresholds; no codes are read.
 template <int NL, bool ES, bool INIT, int DV>
-__device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int s0, int lane,
+__device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int off, int lane,
                                            const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
-                                           uint8_t *__restrict__ v2c, float a, const float *lut_s,
-                                           const float *__restrict__ beta_next, const int *__restrict__ beta_slot,
+                                           uint8_t *__restrict__ v2c, float a, int ev, float bv,
                                            const unsigned (&tb)[8], uint64_t *__restrict__ bitsT, const Frozen<4> &fz)
 {
     constexpr int VEC = 4, W = kWave * VEC;
@@ -1221,14 +1220,16 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
     int e[D];
     float bb[D];
     unsigned q[D];
+    // edge ids and betas of this variable: lanes off .. off + DV - 1 of the wave's prefetched index registers
 #pragma unroll
-    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+    for (int k = 0; k < DV; ++k) {
+        e[k] = __builtin_amdgcn_readlane(ev, off + k);
+        bb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), off + k));
+    }
 #pragma unroll
     for (int k = 0; k < DV; ++k)
         q[k] = INIT ? 0u : __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(c2v + (tileE + e[k]) * W + lane_off)) << 2;
     const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
-#pragma unroll
-    for (int k = 0; k < DV; ++k) bb[k] = beta_next[beta_slot[e[k]]];
 
     unsigned keys[D], sgns[D];
 #pragma unroll
@@ -1318,15 +1319,29 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
     unsigned tb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) tb[q] = (q < n_levels) ? __float_as_uint(thr_next[q]) : 0x7fc00000u;
+    // Index data of the wave's VPW variables, fetched ONCE with the lanes in parallel (degrees <= 8: at most 64 edges):
+    // var_ptr[jbase .. jbase + VPW] -> CSC edge ids -> beta slots -> betas, alpha slots -> alphas.  Per variable these would
+    // be three dependent scalar round trips in front of the row loads; here the variables only pick lanes (v_readlane).
+    static_assert(VPW <= 8, "edge ids of a wave's variables are held one per lane");
+    const int nv = min(VPW, g.n - jbase);
+    const int vp = g.var_ptr[min(jbase + min(lane, VPW), g.n)];
+    const int s_base = __builtin_amdgcn_readfirstlane(vp);
+    const int n_edges = __builtin_amdgcn_readlane(vp, nv) - s_base;
+    int ev = 0;
+    float bv = 0.0f, av = 0.0f;
+    if (lane < n_edges) {
+        ev = g.csc_edge[s_base + lane];
+        bv = beta_next[beta_slot[ev]];
+    }
+    if (!INIT && lane < nv) av = alpha_row[alpha_slot[jbase + lane]];
 #pragma unroll 1
-    for (int u = 0; u < VPW; ++u) {
+    for (int u = 0; u < nv; ++u) {
         const int j = jbase + u;
-        if (j >= g.n) break;
-        const int s0 = uni(g.var_ptr[j]);
-        const int dv = uni(g.var_ptr[j + 1]) - s0;
-        const float a = INIT ? 0.0f : alpha_row[alpha_slot[j]];
+        const int s0 = __builtin_amdgcn_readlane(vp, u);
+        const int dv = __builtin_amdgcn_readlane(vp, u + 1) - s0;
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), u));
 #define LDPC_VQ_CASE(D) \
-    case D: vn_q4_body<NL, ES, INIT, D>(g, tile, j, s0, lane, c2v, llrT, v2c, a, lut_s, beta_next, beta_slot, tb, bitsT, fz); break;
+    case D: vn_q4_body<NL, ES, INIT, D>(g, tile, j, s0 - s_base, lane, c2v, llrT, v2c, a, ev, bv, tb, bitsT, fz); break;
         switch (dv) {
             LDPC_VQ_CASE(0) LDPC_VQ_CASE(1) LDPC_VQ_CASE(2) LDPC_VQ_CASE(3) LDPC_VQ_CASE(4)
             LDPC_VQ_CASE(5) LDPC_VQ_CASE(6) LDPC_VQ_CASE(7) LDPC_VQ_CASE(8)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # code-pair form with the LLR -> V2C-code pass in front of iteration 0 (instead of the fp32 check sweep on gathered LLR rows)
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/pair4; rm -rf $O; mkdir -p $O
+O=gpurun_out/pair5; rm -rf $O; mkdir -p $O
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q > $O/pytest.log 2>&1; rc=$?; echo "rc=$rc" >> $O/pytest.log; tail -5 $O/pytest.log
 [ $rc = 0 ] || exit $rc
 for mode in pair pair; do
@@ -11,6 +11,6 @@ for mode in pair pair; do
 done
 python - <<'PY'
 import json
-for l in open("gpurun_out/pair4/time.jsonl"):
+for l in open("gpurun_out/pair5/time.jsonl"):
     d = json.loads(l); print(d["tag"], d["workload"], round(d["decode_ms"], 3), round(d.get("cn_ms", 0), 4), round(d.get("vn_ms", 0), 4))
 PY
