@@ -16,7 +16,11 @@ environment) the script spawns its N ranks itself as child processes BEFORE anyt
 GPU, relays rank 0's JSON line and exits non-zero if a rank fails; started under
 torch.distributed.run it is one of the ranks.  Weak scaling by default (every rank decodes its own
 batch; `--strong` splits --batch over the ranks); every step ends with the RCCL all-gather of
-the bit-packed hard decisions; value = all ranks' codewords / max-rank time.
+the bit-packed hard decisions; value = all ranks' codewords / max-rank time.  A multi-rank line also
+carries `distributed` (world size / backend as the process group reports them, every rank's device,
+the all-gather timed alone, a content check of the gathered array on every rank) and
+`sharded_workloads`: BASELINE config 5 -- (16200,7200) W-RCQ, T=20 -- weak (32768 per GPU) and strong
+(262144 in total) with the same all-gather per step; rank 0 adds roofline and cpu_baseline as at N=1.
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
   roofline     : the dominant kernel of the timed step, timed live with HIP events on its stream.
@@ -75,6 +79,10 @@ def parse_args(argv=None):
                     help="initialise the process group and run the all-gather path even with one rank (checks the RCCL plumbing on a single GPU)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --batch (default: the workload's) is the TOTAL over all GPUs, split evenly")
+    ap.add_argument("--config5-total", type=int, default=262144,
+                    help="total codewords of the strong-scaling config-5 leg of a multi-rank run (BASELINE.json: 262144)")
+    ap.add_argument("--config5-max-per-gpu", type=int, default=262144,
+                    help="skip that leg when total / N exceeds this many codewords per GPU (memory: ~0.42 MB per codeword)")
     return ap.parse_args(argv)
 
 
@@ -87,24 +95,47 @@ def free_port():
 
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` started bare: run the N ranks as CHILD processes (one per GPU) and relay rank 0's
-    JSON line.  This parent never touches the GPU (no HIP call, no torch.cuda call) -- nothing is re-exec'ed."""
+    JSON line.  This parent never touches the GPU (no HIP call, no torch.cuda call) -- nothing is re-exec'ed.
+    All children are polled: the first rank that exits non-zero ends the run (the others are killed, not left waiting
+    in a collective until the process-group timeout), and every rank's stderr is kept and shown on failure."""
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(free_port())
-    procs = []
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode(errors="replace")
-    codes = [p.wait() for p in procs]
-    lines = [l for l in out0.splitlines() if l.startswith("{")]
-    if any(codes) or len(lines) != 1:
-        sys.stderr.write(f"bench.py: rank exit codes {codes}, {len(lines)} result line(s)\n")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+                break
+        else:
+            time.sleep(0.2)
+    if failed is not None:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        raise SystemExit(1)
+    codes = [p.wait() for p in procs]
+    out0.seek(0)
+    lines = [l for l in out0.read().decode(errors="replace").splitlines() if l.startswith("{")]
+    if any(codes) or len(lines) != 1:
+        sys.stderr.write(f"bench.py: rank exit codes {codes}, {len(lines)} result line(s)\n")
+        for r, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read().decode(errors="replace")[-3000:]
+            if tail.strip():
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
+        rc = codes[failed] if failed is not None else next((c for c in codes if c), 1)
+        raise SystemExit(rc if 0 < rc < 256 else 1)
+    for r, f in enumerate(errs):                      # relay the ranks' diagnostics (warnings, RCCL banner) to our stderr
+        f.seek(0)
+        sys.stderr.write(f.read().decode(errors="replace"))
     print(lines[0], flush=True)
 
 
@@ -408,6 +439,180 @@ def measure_leg(workload, device, snr_db, steps, reps, copy_gbs, with_cpu, torch
     return leg
 
 
+class ShardedRun:
+    """One workload on this rank's GPU, every step ending with the all-gather of the bit-packed hard decisions
+    (RCCL over xGMI with backend "nccl"; gloo = host-side rehearsal on a one-GPU box).  All ranks construct and drive
+    their ShardedRun objects in the same order -- every method that talks to the process group is collective."""
+
+    def __init__(self, workload, B, ctx, early, overlap, snr_db):
+        import torch
+        self.torch, self.ctx = torch, ctx
+        self.workload, self.B, self.early, self.overlap = workload, int(B), bool(early), bool(overlap)
+        gname, self.T, _, self.dtype, self.desc = WORKLOADS[workload]
+        self.gname = gname
+        self.eng, self.dec, self.code = build_decoder(workload, ctx["device"])
+        self.g = self.code.tanner_graph()
+        self.llr = make_llr(self.B, self.g.n, snr_db, 1234 + ctx["rank"], ctx["device"],
+                            torch.float64 if self.dtype == "f64" else torch.float32)
+        self.want_post = wants_posterior(workload)
+        self.nbytes = (self.g.n + 7) // 8
+        self.pending = []          # [(work, gathered, packed_src)] -- the previous step's all-gather, still in flight
+        self.res = self.gathered = None
+
+    def step(self):
+        """decode this rank's shard, then all-gather the bit-packed hard decisions.  Overlapped form: the gather of step k
+        runs on RCCL's stream while step k+1 decodes (separate buffers), and is joined one step later."""
+        import torch.distributed as dist
+        from sharding import all_gather_hard_decisions
+        ctx, torch = self.ctx, self.torch
+        res = self.eng.decode(self.llr, early_stop=self.early, want_bits=True, want_posterior=self.want_post,
+                              want_packed=ctx["use_dist"])
+        gathered = None
+        if ctx["use_dist"]:
+            total = self.B * ctx["world"]
+            if ctx["backend"] != "nccl":                           # rehearsal path: host-side gather
+                gathered = all_gather_hard_decisions(res.packed_bits.cpu(), total)
+            elif not self.overlap:
+                gathered = all_gather_hard_decisions(res.packed_bits, total)
+            else:
+                if self.pending:
+                    self.pending.pop()[0].wait()
+                gathered = torch.empty((total, self.nbytes), dtype=torch.uint8, device=ctx["device"])
+                work = dist.all_gather_into_tensor(gathered, res.packed_bits, async_op=True)
+                self.pending.append((work, gathered, res.packed_bits))
+        self.res, self.gathered = res, gathered
+        return res, gathered
+
+    def fence(self):
+        import torch.distributed as dist
+        while self.pending:
+            self.pending.pop()[0].wait()
+        if self.ctx["use_dist"]:
+            dist.barrier()
+        self.torch.cuda.synchronize(self.ctx["device"])
+
+    def timed(self, steps, warmup):
+        """-> seconds for `steps` steps, MAX over ranks (barrier + device synchronise on both sides)"""
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        return max_over_ranks(time.perf_counter() - t0, self.ctx)
+
+    def gather_alone(self, reps=3):
+        """the all-gather of one step's hard decisions by itself (nothing overlapped): barrier, synchronise, gather,
+        synchronise -- MAX over ranks per repetition; -> {"ms": best, "ms_all": [...], bytes, rates} or None"""
+        ctx = self.ctx
+        if not ctx["use_dist"] or self.res is None or self.res.packed_bits is None:
+            return None
+        from sharding import all_gather_hard_decisions
+        src = self.res.packed_bits if ctx["backend"] == "nccl" else self.res.packed_bits.cpu()
+        total = self.B * ctx["world"]
+        times = []
+        for _ in range(reps + 1):                                   # first repetition: communicator warm-up, dropped
+            self.fence()
+            t0 = time.perf_counter()
+            out = all_gather_hard_decisions(src, total)
+            self.torch.cuda.synchronize(ctx["device"])
+            times.append(1e3 * max_over_ranks(time.perf_counter() - t0, ctx))
+        del out
+        times = times[1:]
+        per_rank = self.B * self.nbytes
+        best = min(times)
+        w = ctx["world"]
+        return {"ms": best, "ms_all": times, "bytes_per_rank": per_rank, "bytes_gathered": per_rank * w,
+                # algorithm bandwidth: gathered bytes / time; bus bandwidth (what one rank's links carry): x (w-1)/w
+                "algbw_GBps": per_rank * w / (best * 1e-3) / 1e9,
+                "busbw_GBps": per_rank * (w - 1) / (best * 1e-3) / 1e9,
+                "method": "barrier + synchronise, ONE all_gather_into_tensor, synchronise; max over ranks, best of %d" % reps}
+
+    def verify(self):
+        """after the last step, on EVERY rank: this rank's shard inside `gathered` equals its local packed_bits, and the
+        byte sums of all shards (all-reduced) equal the byte sum of the gathered array -> dict (raises on mismatch)"""
+        import torch.distributed as dist
+        ctx, torch = self.ctx, self.torch
+        res, gathered = self.res, self.gathered
+        T = self.T
+        its = res.iterations
+        assert int(its.min().item()) >= 1 and int(its.max().item()) <= T
+        if not self.early:
+            assert int(its.min().item()) == T                         # nothing skipped: every iteration ran
+        out = {"converged_fraction": float(res.success.float().mean().item())}
+        if ctx["use_dist"] and gathered is not None:
+            world, rank = ctx["world"], ctx["rank"]
+            assert tuple(gathered.shape) == (world * self.B, self.nbytes)
+            mine = gathered[rank * self.B:(rank + 1) * self.B]
+            local = res.packed_bits.to(mine.device)
+            own_ok = bool(torch.equal(mine, local))
+            dev = ctx["device"] if ctx["backend"] == "nccl" else "cpu"
+            sums = torch.tensor([int(local.to(torch.int64).sum().item()), int(own_ok)], dtype=torch.int64, device=dev)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            total_sum = int(gathered.to(torch.int64).sum().item())
+            out["gather_check"] = {"own_shard_equal_on_ranks": int(sums[1].item()), "ranks": world,
+                                   "sum_of_shard_checksums": int(sums[0].item()), "checksum_of_gathered": total_sum,
+                                   "ok": bool(int(sums[1].item()) == world and int(sums[0].item()) == total_sum)}
+            if not out["gather_check"]["ok"]:
+                raise SystemExit(f"all-gather content check failed on rank {rank}: {out['gather_check']}")
+        return out
+
+    def release(self):
+        self.fence()
+        self.eng = self.dec = self.llr = self.res = self.gathered = None
+        self.torch.cuda.empty_cache()
+
+
+def max_over_ranks(x, ctx):
+    if not ctx["use_dist"]:
+        return float(x)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=ctx["device"] if ctx["backend"] == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def rank_inventory(ctx):
+    """what the process group really is (not what the environment said): world size and backend as torch.distributed
+    reports them, and every rank's device (index, name, PCI bus id / uuid where this torch exposes them)"""
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(ctx["device"])
+    me = {"rank": ctx["rank"], "device_index": ctx["device"].index, "name": p.name, "pid": os.getpid(),
+          "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+    for k in ("pci_bus_id", "pci_device_id", "pci_domain_id", "uuid", "gcnArchName"):
+        v = getattr(p, k, None)
+        if v is not None:
+            me[k] = v if isinstance(v, (int, float)) else str(v)
+    if not ctx["use_dist"]:
+        return {"world_size": 1, "backend": None, "ranks": [me]}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, me)
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": everyone}
+
+
+def sharded_leg(workload, B, strong, ctx, args):
+    """BASELINE config 5 inside the multi-rank line: a short sharded measurement (weak: B per GPU; strong: B total), every
+    step ending in the all-gather; collective on every rank, the dict matters on rank 0"""
+    world = ctx["world"]
+    per = B // world if strong else B
+    run = ShardedRun(workload, per, ctx, early=False, overlap=not args.no_overlap, snr_db=args.snr_db)
+    steps = max(args.leg_steps, 1)
+    elapsed = run.timed(steps, 1)
+    ver = run.verify()
+    ga = run.gather_alone()
+    info = run.eng.info()
+    leg = {"workload": f"{run.desc}, {run.T} iterations, batch {per}/GPU x {world} GPUs, SNR {args.snr_db} dB, fixed-iteration "
+                       f"flooding decode + all-gather of the bit-packed hard decisions",
+           "scaling": "strong" if strong else "weak", "dtype": run.dtype, "batch_per_gpu": per, "global_batch": per * world,
+           "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "value": per * world * steps / elapsed, "unit": "codewords/s",
+           "engine": info, "allgather": ga, **ver}
+    run.release()
+    return leg
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -444,6 +649,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+        world, rank = dist.get_world_size(), dist.get_rank()        # from here on: what the process group says
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")
+    ctx = {"device": device, "rank": rank, "world": world, "backend": backend, "use_dist": use_dist}
 
     gname, T, default_batch, dtype, desc = WORKLOADS[args.workload]
     B = args.batch or default_batch
@@ -451,64 +660,17 @@ def main():
         if B % world:
             raise SystemExit(f"--strong: total batch {B} is not divisible by {world} GPUs")
         B //= world
-    eng, dec, code = build_decoder(args.workload, device)
-    g = code.tanner_graph()
-    llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device, torch.float64 if dtype == "f64" else torch.float32)
-    want_post = wants_posterior(args.workload)
     early = bool(args.early_stop)
+    main_run = ShardedRun(args.workload, B, ctx, early=early, overlap=not args.no_overlap, snr_db=args.snr_db)
+    eng, dec, code, g, llr = main_run.eng, main_run.dec, main_run.code, main_run.g, main_run.llr
+    want_post = main_run.want_post
 
-    from sharding import all_gather_hard_decisions
-    nbytes = (g.n + 7) // 8
-    pending = []          # [(work, gathered, packed_src)] -- the previous step's all-gather, still in flight
-
-    def step():
-        """decode this rank's shard, then all-gather the bit-packed hard decisions.  The gather of step k
-        runs on RCCL's stream while step k+1 decodes (separate buffers), and is joined one step later."""
-        res = eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post, want_packed=use_dist)
-        gathered = None
-        if use_dist:
-            if backend != "nccl":                                  # rehearsal path: host-side gather
-                gathered = all_gather_hard_decisions(res.packed_bits.cpu(), B * world)
-            elif args.no_overlap:
-                gathered = all_gather_hard_decisions(res.packed_bits, B * world)
-            else:
-                if pending:
-                    pending.pop()[0].wait()
-                gathered = torch.empty((world * B, nbytes), dtype=torch.uint8, device=device)
-                work = dist.all_gather_into_tensor(gathered, res.packed_bits, async_op=True)
-                pending.append((work, gathered, res.packed_bits))
-        return res, gathered
-
-    def fence():
-        while pending:
-            pending.pop()[0].wait()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, gathered = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = main_run.timed(args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
-
-    # sanity on the last step's outputs (nothing skipped): all iterations ran, outputs are binary
-    its = res.iterations
-    assert int(its.min().item()) >= 1 and int(its.max().item()) <= T
-    if not early:
-        assert int(its.min().item()) == T
-    frac_ok = float(res.success.float().mean().item())
-    if use_dist and gathered is not None:
-        assert tuple(gathered.shape) == (world * B, nbytes)
+    ver = main_run.verify()                                       # nothing skipped; gathered == the ranks' shards
+    inventory = rank_inventory(ctx)
+    allgather = main_run.gather_alone()
 
     out = {
         "metric": METRIC,
@@ -520,13 +682,42 @@ def main():
                    "graph": gname, "n": g.n, "m": g.m, "edges": g.E, "iterations": T,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": ("all_gather(bit-packed hard decisions), " + backend) if use_dist else "none",
-                   "converged_fraction": frac_ok,
+                   "overlap": (not args.no_overlap) if use_dist else None,
+                   "converged_fraction": ver["converged_fraction"],
                    "dtype_note": "the reference's BasicMinSumDecoder computes in float64 (numpy default); the benchmark "
                                  "config is defined on fp32 (BASELINE.json north_star, SURVEY 8d) -- the float64 kernels "
                                  "run as the `basic_f64` leg; fp32-vs-fp64 decision mismatch rates are in BASELINE.md"},
     }
+    if use_dist:
+        out["distributed"] = {**inventory, "allgather": allgather, "gather_check": ver.get("gather_check"),
+                              "step": "decode of this rank's shard, then all_gather_into_tensor of uint8[B, ceil(n/8)]; "
+                                      + ("the gather of step k overlaps the decode of step k+1 (joined one step later)"
+                                         if not args.no_overlap else "joined before the next decode (--no-overlap)")}
+
+    # BASELINE config 5 as written, inside the multi-rank line (every rank takes part): weak 32768/GPU and strong 262144 total
+    sharded = {}
+    default_line = args.workload == "basic" and not args.batch and not early and not args.strong
+    if use_dist and not args.no_legs and default_line:
+        main_run.fence()
+        llr = None
+        main_run.res = main_run.gathered = None
+        main_run.llr = None                                       # make room: the strong leg holds 262144 / N codewords per GPU
+        torch.cuda.empty_cache()
+        sharded["wrcq_dvbs2_weak"] = sharded_leg("wrcq_dvbs2", WORKLOADS["wrcq_dvbs2"][2], False, ctx, args)
+        total = args.config5_total
+        if total % world == 0 and total // world <= args.config5_max_per_gpu:
+            sharded["wrcq_dvbs2_strong"] = sharded_leg("wrcq_dvbs2", total, True, ctx, args)
+        else:
+            sharded["wrcq_dvbs2_strong"] = {"skipped": f"{total} codewords over {world} GPUs = {total / world:.0f} per GPU "
+                                                       f"(limit {args.config5_max_per_gpu})"}
+        llr = make_llr(B, g.n, args.snr_db, 1234 + rank, device, torch.float64 if dtype == "f64" else torch.float32)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()                              # rank 0's single-GPU extras below need no group
 
     if rank == 0:
+        if sharded:
+            out["sharded_workloads"] = sharded
         out["config"]["engine"] = eng.info()
         reps = max(args.sweep_reps, 1)
         bm = byte_model(args.workload, g, T, B)
@@ -552,12 +743,12 @@ def main():
         else:
             out["roofline"] = stream_roofline(eng, args.workload, g, T, B, llr, reps, copy_gbs, torch)
         out["decode_algorithmic_GBps"] = bm["decode"] / (ms_per_step * 1e-3) / 1e9
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)
-        if world == 1 and not use_dist and not args.no_legs and args.workload == "basic" and not args.batch and not early:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, dec, code, args.snr_db)     # rank 0's host cores, any N
+        if not use_dist and not args.no_legs and default_line:
             # the other BASELINE configs, bounded (a few steps each), so that one driver run carries every config
-            del llr, res
-            torch.cuda.empty_cache()
+            del llr
+            main_run.release()
             out["workloads"] = {}
             for w in LEGS:
                 out["workloads"][w] = measure_leg(w, device, args.snr_db, max(args.leg_steps, 1), reps, copy_gbs,
@@ -566,9 +757,6 @@ def main():
         os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

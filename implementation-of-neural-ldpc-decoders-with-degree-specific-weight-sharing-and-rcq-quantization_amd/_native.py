@@ -38,23 +38,69 @@ class NativeEngineError(RuntimeError):
     pass
 
 
+SOURCES = ("ldpc_hip.hip", "ldpc_kernels.hip", "ldpc_resident.hip", "ldpc_train.hip", "ldpc_layered.hip")
+
+
+def _source_files():
+    return [os.path.join(CSRC, f) for f in SOURCES] + [HEADER, DEBUG_HEADER]
+
+
+def source_hash(defines=()) -> str:
+    """sha256 over the compile recipe (flags, defines) and the CONTENT of every source the library is built from.
+    File times say nothing after a copy to another machine; this does."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(("\0".join(HIPCC_FLAGS) + "\1" + "\0".join(sorted(defines))).encode())
+    for path in _source_files():
+        h.update(b"\2" + os.path.basename(path).encode() + b"\3")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _hash_path(target: str) -> str:
+    return target + ".srchash"
+
+
+def built_hash(target: Optional[str] = None) -> Optional[str]:
+    """the source hash recorded beside a built library (None: no record)"""
+    try:
+        with open(_hash_path(target or os.path.join(_HERE, LIB_NAME))) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
+def is_stale(target: Optional[str] = None, defines=()) -> bool:
+    target = target or os.path.join(_HERE, LIB_NAME)
+    return not os.path.exists(target) or built_hash(target) != source_hash(defines)
+
+
 def build_native(force: bool = False, verbose: bool = False, defines=(), out: Optional[str] = None) -> str:
-    """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir.
+    """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir; skipped when the library on disk was
+    built from exactly these sources with exactly this recipe (content hash stored in <lib>.srchash, not file times).
     `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
-    srcs = [os.path.join(CSRC, "ldpc_hip.hip"), os.path.join(CSRC, "ldpc_kernels.hip"),
-            os.path.join(CSRC, "ldpc_resident.hip"), os.path.join(CSRC, "ldpc_train.hip"), HEADER, DEBUG_HEADER]
+    srcs = _source_files()
     target = out or os.path.join(_HERE, LIB_NAME)
-    if not force and os.path.exists(target) and all(
-            os.path.getmtime(target) >= os.path.getmtime(s) for s in srcs):
+    want = source_hash(defines)
+    if not force and os.path.exists(target) and built_hash(target) == want:
         return target
     hipcc = os.environ.get("HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", target, srcs[0]]
+    tmp = target + ".tmp%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", tmp, srcs[0]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
         print(res.stdout + res.stderr)
     if res.returncode != 0:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
         raise NativeEngineError("hipcc failed:\n" + res.stderr[-4000:])
+    os.replace(tmp, target)                      # never a half-written library under the real name
+    with open(_hash_path(target), "w") as f:
+        f.write(want + "\n")
     return target
 
 
@@ -94,6 +140,10 @@ def load():
             raise NativeEngineError(
                 f"{LIB_NAME} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(hipcc --offload-arch=gfx950) -- there is no CPU fallback for the decode path")
+        if "LDPC_HIP_LIB" not in os.environ and is_stale(LIB_PATH):
+            raise NativeEngineError(
+                f"{LIB_PATH} was not built from the sources in csrc/ (content hash {built_hash(LIB_PATH)} != "
+                f"{source_hash()}): run `python -c 'import __graft_entry__ as g; g.build()'` -- a stale engine is never loaded")
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:

@@ -6,6 +6,7 @@
 #include "ldpc_kernels.hip"
 #include "ldpc_resident.hip"
 #include "ldpc_train.hip"
+#include "ldpc_layered.hip"
 
 #include <algorithm>
 #include <mutex>
@@ -112,11 +113,18 @@ struct ldpc_decoder {
     bool pair_ok = false;          // RCQ code-pair form (vn_sweep_q / cn_sweep_q): one beta per check, sorted thresholds
     int4 *gat_meta = nullptr;      // [E + 1]
     int *gat_nbr = nullptr;        // [sum dv(dv-1) + 8]
+    // LDS-resident layered decode (ldpc_layered.hip): LDPC_SCHED_LAYERED_REF on codes whose posteriors fit LDS
+    bool lay_ok = false;
+    LayeredPlan lay{};
+    uint32_t *lay_off = nullptr;
+    size_t lay_lds = 0;
 };
 
 namespace {
 
 bool use_resident(const ldpc_decoder *d) { return d->res_ok && (d->mode == LDPC_MODE_AUTO || d->mode == LDPC_MODE_RESIDENT); }
+// layered schedule: the LDS-resident kernel unless a streaming mode is forced (then layered_rcq, posteriors in HBM)
+bool use_layered_lds(const ldpc_decoder *d) { return d->lay_ok && (d->mode == LDPC_MODE_AUTO || d->mode == LDPC_MODE_RESIDENT); }
 // streaming engine, RCQ: one fused kernel per iteration (cn_gather) unless the two-sweep form is forced
 // streaming forms of an fp32 RCQ decoder, best first: code pair (4E + 4n bytes per iteration), fused gather, two sweeps
 bool use_pair(const ldpc_decoder *d) { return d->pair_ok && d->mode != LDPC_MODE_SWEEPS && d->mode != LDPC_MODE_GATHER; }
@@ -997,6 +1005,85 @@ int decode_resident(const ldpc_decoder *d, const void *llr, int64_t batch, int32
     }
 }
 
+// ---- LDS-resident layered decode: plan (host) and launch -----------------------------------------------------
+int build_layered_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
+{
+    const ldpc_graph *g = d->g;
+    d->lay_ok = false;
+    if (d->schedule != LDPC_SCHED_LAYERED_REF || d->form != LDPC_C2V_RCQ || d->dtype != LDPC_F32) return LDPC_OK;
+    if (g->E == 0 || g->m == 0 || g->max_dc > 64) return LDPC_OK;     // a check wider than a wavefront: streaming kernel
+    int lw = 1;
+    while (lw < g->max_dc) lw <<= 1;
+    int cw = 64 / lw;
+    while (cw > 1 && (size_t)cw * lay_row_bytes(g->n) > kLdsBytes) cw >>= 1;
+    if ((size_t)cw * lay_row_bytes(g->n) > kLdsBytes) return LDPC_OK;  // one codeword's posteriors exceed LDS
+    const int m_pad = (g->m + kLayPf - 1) / kLayPf * kLayPf;
+    const uint32_t none = (uint32_t)g->n * 4u;                        // the codeword's +inf word
+    std::vector<uint32_t> off((size_t)(m_pad + kLayPf) * lw, none);
+    bool deg1 = false;
+    for (int i = 0; i < g->m; ++i) {
+        const int e0 = g->h_check_ptr[i], dc = g->h_check_ptr[i + 1] - e0;
+        deg1 = deg1 || dc == 1;
+        for (int t = 0; t < lw; ++t) {
+            uint32_t o = t < dc ? (uint32_t)g->h_var_idx[e0 + t] * 4u : none;
+            off[(size_t)i * lw + t] = o | (dc == 1 ? 0x80000000u : 0u);
+        }
+    }
+    // magnitude 0 reconstructs to 0 under every quantiser (rcq_decoder.py:79-85, :107-119): tau_0 == 0 and no later
+    // threshold <= 0 -- true for the reference's C * (j / (2^(bc-1) - 1))^gamma with gamma > 0
+    bool zero0 = true;
+    for (int q = 0; q < d->n_quant; ++q) {
+        float rec = desc->thresholds[(size_t)q * d->n_levels];
+        for (int k = 1; k < d->n_levels; ++k)
+            if (0.0f >= desc->thresholds[(size_t)q * d->n_levels + k]) rec = desc->thresholds[(size_t)q * d->n_levels + k];
+        zero0 = zero0 && rec == 0.0f;
+    }
+    int rc = upload(&d->lay_off, off.data(), off.size());
+    if (rc) return rc;
+    d->lay = LayeredPlan{g->n, g->m, lw, cw, m_pad, deg1 ? 1 : 0, zero0 ? 1 : 0, d->lay_off};
+    d->lay_lds = (size_t)cw * lay_row_bytes(g->n);
+    d->lay_ok = true;
+    return LDPC_OK;
+}
+
+int decode_layered_lds(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop, int32_t *bits,
+                       void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed_bits, void *stream)
+{
+    DeviceGuard guard(d->g->device);
+    hipStream_t s = (hipStream_t)stream;
+    const LayeredPlan &pl = d->lay;
+    const unsigned blocks = (unsigned)((batch + pl.cw - 1) / pl.cw);
+#define LDPC_LAY_K(LW_, NL_, ES_, D1_, Z0_)                                                                          \
+    do {                                                                                                             \
+        auto kfn = layered_lds<LW_, NL_, ES_, D1_, Z0_>;                                                             \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                   \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kWave), d->lay_lds, s, pl, (const float *)llr, (long long)batch, \
+                           (const float *)d->thresholds, d->n_levels, (const int *)d->q_of_iter_dev, d->T,           \
+                           bits, (float *)posterior, iterations, success, packed_bits);                             \
+    } while (0)
+    // the common case (bc = 3, no degree-1 check, zero reconstructs to zero) gets the lean instantiation per stop mode;
+    // everything else the general one (run-time level count, degree-1 flag, the reference's "w < 0" sign test)
+#define LDPC_LAY_NL(LW_)                                                                                             \
+    do {                                                                                                             \
+        const bool lean = d->n_levels == 4 && !pl.has_deg1 && pl.zero0;                                              \
+        if (lean) { if (early_stop) LDPC_LAY_K(LW_, 4, true, false, true); else LDPC_LAY_K(LW_, 4, false, false, true); } \
+        else { if (early_stop) LDPC_LAY_K(LW_, 0, true, true, false); else LDPC_LAY_K(LW_, 0, false, true, false); } \
+    } while (0)
+    switch (pl.lw) {
+    case 1: LDPC_LAY_NL(1); break;
+    case 2: LDPC_LAY_NL(2); break;
+    case 4: LDPC_LAY_NL(4); break;
+    case 8: LDPC_LAY_NL(8); break;
+    case 16: LDPC_LAY_NL(16); break;
+    case 32: LDPC_LAY_NL(32); break;
+    default: LDPC_LAY_NL(64); break;
+    }
+#undef LDPC_LAY_NL
+#undef LDPC_LAY_K
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
 }  // namespace
 
 // =========================================================================================== C ABI
@@ -1241,6 +1328,7 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
     }
     resident_table_flags(d, desc->alpha, d->form == LDPC_C2V_RCQ ? desc->thresholds : nullptr);
     if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
+    if (!rc) rc = build_layered_plan(d, desc);
     if (rc) {
         ldpc_decoder_destroy(d);
         return rc;
@@ -1263,7 +1351,7 @@ int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
     if (mode == LDPC_MODE_PAIR && !d->pair_ok)
         return fail(LDPC_ERR_UNSUPPORTED, "the code-pair form needs an fp32 flooding RCQ decoder with one beta per check, "
                                           "sorted thresholds and at most 62 levels");
-    if (mode == LDPC_MODE_RESIDENT && !d->res_ok)
+    if (mode == LDPC_MODE_RESIDENT && !d->res_ok && !d->lay_ok)
         return fail(LDPC_ERR_UNSUPPORTED, "code does not qualify for the LDS-resident engine "
                                           "(dv <= 8, check degree <= 1024, state within 160 KiB of LDS)");
     d->mode = mode;
@@ -1273,10 +1361,11 @@ int ldpc_decoder_set_mode(ldpc_decoder *d, int32_t mode)
 int ldpc_decoder_info(const ldpc_decoder *d, int32_t out4[4])
 {
     if (!d || !out4) return fail(LDPC_ERR_ARG, "NULL argument");
-    out4[0] = use_resident(d) ? LDPC_MODE_RESIDENT : use_pair(d) ? LDPC_MODE_PAIR : use_gather(d) ? LDPC_MODE_GATHER : LDPC_MODE_SWEEPS;
+    out4[0] = (use_resident(d) || use_layered_lds(d)) ? LDPC_MODE_RESIDENT : use_pair(d) ? LDPC_MODE_PAIR : use_gather(d) ? LDPC_MODE_GATHER : LDPC_MODE_SWEEPS;
     out4[1] = d->res_ok ? (d->dtype == LDPC_F64 ? 1 : d->res_G) : 0;      // fp64: one codeword in a float pair's slots
     out4[2] = d->res_ok ? d->res_NT : 0;
     out4[3] = d->res_ok ? (int32_t)d->res_lds : 0;
+    if (d->lay_ok) { out4[1] = d->lay.cw; out4[2] = kWave; out4[3] = (int32_t)d->lay_lds; }   // layered: codewords per (one-wave) workgroup
     return LDPC_OK;
 }
 
@@ -1308,7 +1397,7 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
     (void)hipFree(d->beta_slot); (void)hipFree(d->alpha_slot); (void)hipFree(d->oms_alpha_slot);
     (void)hipFree(d->thresholds); (void)hipFree(d->lut); (void)hipFree(d->q_of_iter_dev);
     for (void *p : d->res_bufs) (void)hipFree(p);
-    (void)hipFree(d->gat_meta); (void)hipFree(d->gat_nbr);
+    (void)hipFree(d->gat_meta); (void)hipFree(d->gat_nbr); (void)hipFree(d->lay_off);
     (void)hipFree(d->beta_inv_ptr); (void)hipFree(d->beta_inv_items); (void)hipFree(d->alpha_inv_ptr);
     (void)hipFree(d->alpha_inv_items); (void)hipFree(d->oms_inv_ptr); (void)hipFree(d->oms_inv_items);
     delete d;
@@ -1317,7 +1406,7 @@ void ldpc_decoder_destroy(ldpc_decoder *d)
 size_t ldpc_decoder_workspace_bytes(const ldpc_decoder *d, int64_t batch)
 {
     if (!d || batch < 0) return 0;
-    if (use_resident(d)) return kAlign;               // the resident engine keeps its state in LDS
+    if (use_resident(d) || use_layered_lds(d)) return kAlign;   // the LDS-resident engines keep their state in LDS
     return carve(d, batch, nullptr).total;
 }
 
@@ -1333,6 +1422,8 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
     if (((uintptr_t)workspace % kAlign) != 0) return fail(LDPC_ERR_ARG, "workspace must be %zu-byte aligned", kAlign);
     if (use_resident(d))
         return decode_resident(d, llr, batch, early_stop, bits, posterior, iterations, success, packed_bits, nullptr, stream);
+    if (use_layered_lds(d))
+        return decode_layered_lds(d, llr, batch, early_stop, bits, posterior, iterations, success, packed_bits, stream);
     const Workspace w = carve(d, batch, workspace);
     if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
     if ((size_t)w.tiles * ((d->g->n + 3) / 4) > 0x7fffffffull) return fail(LDPC_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -1526,7 +1617,7 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])
 {
     if (!d || !out8 || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
-    if (use_resident(d)) return fail(LDPC_ERR_ARG, "workspace layout exists only in LDPC_MODE_STREAM");
+    if (use_resident(d) || use_layered_lds(d)) return fail(LDPC_ERR_ARG, "workspace layout exists only in LDPC_MODE_STREAM");
     char *base = reinterpret_cast<char *>(kAlign);   // any non-null base: only differences are used
     const Workspace w = carve(d, batch, base);
     out8[0] = w.vec; out8[1] = w.tiles;
@@ -1551,7 +1642,7 @@ int ldpc_debug_sweep(const ldpc_decoder *d, int64_t batch, int32_t which, int32_
 {
     if (!d || !workspace || batch <= 0) return fail(LDPC_ERR_ARG, "bad argument");
     if (iter < 0 || iter >= d->T) return fail(LDPC_ERR_ARG, "iter outside [0, T)");
-    if (use_resident(d)) return fail(LDPC_ERR_ARG, "debug sweeps need LDPC_MODE_STREAM");
+    if (use_resident(d) || use_layered_lds(d)) return fail(LDPC_ERR_ARG, "debug sweeps need LDPC_MODE_STREAM");
     const Workspace w = carve(d, batch, workspace);
     if (w.total > workspace_bytes) return fail(LDPC_ERR_WORKSPACE, "workspace too small");
     DeviceGuard guard(d->g->device);

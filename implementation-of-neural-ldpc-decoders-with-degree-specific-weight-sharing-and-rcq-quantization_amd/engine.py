@@ -12,9 +12,11 @@ flatten their reference-style parameters into the tables this class uploads.
 
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -49,7 +51,9 @@ def _require_gpu(device) -> torch.device:
 
 
 class _NativeGraph:
-    """ldpc_graph* for (graph, device); shared by all engines on that graph."""
+    """ldpc_graph* for (graph, device); shared by all engines on that graph.  The cache holds the host graph WEAKLY: when
+    the TannerGraph object dies its entries are evicted, and the device copy is destroyed (ldpc_graph_destroy) as soon as
+    no engine uses it either -- a sweep over many codes does not accumulate device memory."""
     _cache = {}
     _lock = threading.Lock()
 
@@ -72,14 +76,24 @@ class _NativeGraph:
             pass
 
     @classmethod
+    def _evict(cls, key):
+        with cls._lock:
+            cls._cache.pop(key, None)
+
+    @classmethod
     def get(cls, graph: TannerGraph, device: torch.device) -> "_NativeGraph":
-        key = (id(graph), device.index)
+        return cls._get(graph, device.index, lambda: cls(graph, device))
+
+    @classmethod
+    def _get(cls, graph, dev_index, make):
+        key = (id(graph), dev_index)
         with cls._lock:
             hit = cls._cache.get(key)
-            if hit is not None and hit[0] is graph:
+            if hit is not None and hit[0]() is graph:
                 return hit[1]
-            ng = cls(graph, device)
-            cls._cache[key] = (graph, ng)
+            ng = make()
+            cls._cache[key] = (weakref.ref(graph), ng)
+            weakref.finalize(graph, cls._evict, key)
             return ng
 
 
@@ -138,8 +152,9 @@ class DecodeEngine:
         # scratch of ldpc_decode, one buffer PER STREAM: the C ABI wants one workspace per decode that may overlap
         # another on the device, and calls from different threads arrive on different (or the same) torch streams --
         # same stream = serialised by the stream, different streams = different buffers.  Guarded by _ws_lock.
-        self._ws = {}
+        self._ws = collections.OrderedDict()       # stream handle -> buffer, least recently used first; at most _WS_MAX
         self._ws_lock = threading.Lock()
+        self._host_lock = threading.Lock()         # staging buffers of decode_host (not held by _workspace callers)
         mode = os.environ.get("LDPC_ENGINE_MODE", "auto")
         try:
             self.set_mode(mode)
@@ -168,7 +183,7 @@ class DecodeEngine:
         'resident' -- every choice gives identical results."""
         nat.check(self._lib.ldpc_decoder_set_mode(self.handle, self._MODES[mode]), "ldpc_decoder_set_mode")
         with self._ws_lock:
-            self._ws = {}
+            self._ws.clear()
         return self
 
     def info(self) -> dict:
@@ -210,17 +225,22 @@ class DecodeEngine:
     def workspace_bytes(self, batch: int) -> int:
         return int(self._lib.ldpc_decoder_workspace_bytes(self.handle, int(batch)))
 
+    _WS_MAX = 4          # workspaces kept (one per recently used stream); a multi-GB buffer each on the big codes
+
     def _workspace(self, batch: int) -> torch.Tensor:
-        """the current stream's scratch buffer (grown on demand, never shared between streams)"""
+        """the current stream's scratch buffer (grown on demand, never shared between streams).  The cache is a small
+        LRU: a caller cycling through short-lived torch streams does not pile up one buffer per stream -- an evicted buffer
+        goes back to torch's caching allocator, which keeps it alive for the work already queued on its stream."""
         need = self.workspace_bytes(batch)
         key = torch.cuda.current_stream(self.device).cuda_stream
         with self._ws_lock:
-            ws = self._ws.get(key)
+            ws = self._ws.pop(key, None)
             if ws is None or ws.numel() < need:
-                self._ws.pop(key, None)
                 ws = None
                 ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                self._ws[key] = ws
+            self._ws[key] = ws                     # most recently used last
+            while len(self._ws) > self._WS_MAX:
+                self._ws.popitem(last=False)
             return ws
 
     def decode(self, llr: torch.Tensor, *, early_stop: bool = True, want_bits: bool = True,
@@ -256,28 +276,32 @@ class DecodeEngine:
     def decode_host(self, llr_host: torch.Tensor, *, early_stop: bool = True, want_posterior: bool = True):
         """Decode a SMALL batch that lives in host memory (the reference's own call: one CPU vector in, CPU results out)
         with one staged copy each way: pinned host buffers and device buffers are kept per engine, the LLRs go up in one
-        async copy, ldpc_decode writes bits / posterior / iterations / success into ONE device block, that block comes
-        back in one async copy, one stream synchronise.  -> (bits int32 [B, n], posterior | None, iterations int32 [B],
-        success bool [B]) as CPU tensors (fresh copies).  Guarded by a lock: the staging buffers are per engine."""
+        async copy, ldpc_decode writes bits / posterior / iterations / success into ONE device block laid out for THIS
+        batch size (a one-codeword call moves ~2n words back, not the 64-row block), that block comes back in one async
+        copy, one stream synchronise.  -> (bits int32 [B, n], posterior | None, iterations int32 [B], success bool [B])
+        as CPU tensors (fresh copies).  The staging buffers have their own lock (decode() on other threads is not
+        blocked while this call waits for the device)."""
         if llr_host.dim() != 2 or llr_host.shape[1] != self.graph.n or llr_host.shape[0] > self.HOST_BATCH_MAX:
             raise ValueError(f"decode_host takes [B <= {self.HOST_BATCH_MAX}, {self.graph.n}] host tensors")
         B, n = llr_host.shape
         es = 4 if self.dtype == torch.float32 else 8
-        with self._ws_lock:
+        with self._host_lock:
             st = getattr(self, "_host_stage", None)
             if st is None:
                 Bm = self.HOST_BATCH_MAX
-                o_bits, o_post = 0, Bm * n * 4
-                o_it = o_post + Bm * n * es
-                o_ok = o_it + Bm * 4
-                total = (o_ok + Bm + 255) // 256 * 256
+                total = (Bm * n * 4 + Bm * n * es + Bm * 4 + Bm + 1024 + 255) // 256 * 256
                 st = {"h_in": torch.empty((Bm, n), dtype=self.dtype, pin_memory=True),
                       "d_in": torch.empty((Bm, n), dtype=self.dtype, device=self.device),
                       "d_out": torch.empty(total, dtype=torch.uint8, device=self.device),
-                      "h_out": torch.empty(total, dtype=torch.uint8, pin_memory=True),
-                      "off": (o_bits, o_post, o_it, o_ok), "ws": None}
+                      "h_out": torch.empty(total, dtype=torch.uint8, pin_memory=True), "ws": None}
                 self._host_stage = st
-            o_bits, o_post, o_it, o_ok = st["off"]
+            # block layout for B rows: bits | posterior | iterations | success, each 256-byte aligned (posterior: its dtype)
+            al = lambda x: (x + 255) // 256 * 256
+            o_bits = 0
+            o_post = al(B * n * 4)
+            o_it = o_post + (al(B * n * es) if want_posterior else 0)
+            o_ok = o_it + al(B * 4)
+            used = o_ok + B
             st["h_in"][:B].copy_(llr_host)
             with torch.cuda.device(self.device):
                 stream = torch.cuda.current_stream(self.device)
@@ -291,7 +315,7 @@ class DecodeEngine:
                                                 C.c_void_p(base + o_it), C.c_void_p(base + o_ok), None,
                                                 C.c_void_p(st["ws"].data_ptr()), st["ws"].numel(),
                                                 C.c_void_p(stream.cuda_stream)), "ldpc_decode")
-                st["h_out"].copy_(st["d_out"], non_blocking=True)
+                st["h_out"][:used].copy_(st["d_out"][:used], non_blocking=True)
                 stream.synchronize()
             h = st["h_out"]
             bits = h[o_bits:o_bits + B * n * 4].view(torch.int32).view(B, n).clone()
@@ -326,22 +350,6 @@ class DecodeEngine:
             raise ValueError(f"llr must have shape [B, {self.graph.n}], got {tuple(llr.shape)}")
         return llr.contiguous()
 
-    # saved-message buffers are GBs: one is kept for reuse (handed back by recycle_saved after backward) instead
-    # of going through the allocator every training step; the scratch of the training calls is cached like _ws
-    def _take_saved(self, nbytes: int) -> torch.Tensor:
-        buf = getattr(self, "_saved_spare", None)
-        self._saved_spare = None
-        if buf is None or buf.numel() < nbytes:
-            buf = None
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return buf
-
-    def recycle_saved(self, saved: torch.Tensor):
-        """give a saved-state buffer back once its backward has run (stream-ordered reuse on the current stream)"""
-        spare = getattr(self, "_saved_spare", None)
-        if spare is None or spare.numel() < saved.numel():
-            self._saved_spare = saved
-
     def _train_workspace(self, batch: int) -> torch.Tensor:
         need = int(self._lib.ldpc_train_workspace_bytes(self.handle, batch))
         ws = getattr(self, "_train_ws", None)
@@ -363,7 +371,8 @@ class DecodeEngine:
         post = torch.empty((B, n), dtype=self.dtype, device=dev)
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
         succ = torch.empty((B,), dtype=torch.uint8, device=dev)
-        saved = self._take_saved(int(self._lib.ldpc_train_saved_bytes(self.handle, max(B, 1))))
+        # the saved messages become a saved tensor of the autograd node (torch_ops.py): allocated per call, freed with the graph
+        saved = torch.empty(int(self._lib.ldpc_train_saved_bytes(self.handle, max(B, 1))), dtype=torch.uint8, device=dev)
         if B > 0:
             ws = self._train_workspace(B)
             with torch.cuda.device(dev):

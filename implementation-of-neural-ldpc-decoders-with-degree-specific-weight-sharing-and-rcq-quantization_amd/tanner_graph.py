@@ -27,7 +27,7 @@ class TannerGraph:
     """Immutable CSR+CSC view of a binary parity-check matrix (host, int32)."""
 
     __slots__ = ("n", "m", "E", "check_ptr", "var_idx", "var_ptr", "csc_edge",
-                 "check_of_edge", "dc", "dv")
+                 "check_of_edge", "dc", "dv", "__weakref__")
 
     def __init__(self, n: int, m: int, rows: np.ndarray, cols: np.ndarray):
         rows = np.asarray(rows, dtype=np.int64).ravel()

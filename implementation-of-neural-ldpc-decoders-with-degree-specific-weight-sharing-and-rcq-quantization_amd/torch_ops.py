@@ -177,6 +177,9 @@ def _train_setup(ctx, inputs, output):
     llr, beta, alpha, engine, early_stop, alpha_is_oms = inputs
     _post, _bits, iters, saved = output
     ctx.engine, ctx.alpha_is_oms = engine, alpha_is_oms
+    # the handle table holds engines weakly; the autograd node keeps ITS engine alive until the graph is freed (the
+    # decoder may be rebuilt or go out of scope between forward and backward -- the reference's graph is self-contained)
+    ctx._engine_obj = _engine(engine)
     ctx.save_for_backward(saved, llr, iters, beta, alpha)
     ctx.set_materialize_grads(False)
 

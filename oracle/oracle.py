@@ -29,11 +29,20 @@ SUM_TORCH, SUM_NUMPY = 0, 1
 
 def build(force: bool = False) -> str:
     """Compile the library with the committed Makefile (gcc only)."""
-    src_newer = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("ldpc_oracle.c", "ldpc_oracle_impl.h", "Makefile"))
-    if force or src_newer:
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ldpc_oracle.c", "ldpc_oracle_impl.h", "Makefile"):          # content, not file times (they do not survive a copy)
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    want, rec = h.hexdigest(), _LIB_PATH + ".srchash"
+    try:
+        have = open(rec).read().strip()
+    except OSError:
+        have = None
+    if force or not os.path.exists(_LIB_PATH) or have != want:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+        with open(rec, "w") as fh:
+            fh.write(want + "\n")
     return _LIB_PATH
 
 

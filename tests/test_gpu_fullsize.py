@@ -140,6 +140,90 @@ def test_sign_symmetry_at_full_batch(family, gpu_device):
     assert float(a.success.float().mean()) > 0.2               # the early-stop latch was exercised
 
 
+def _oracle_rows(B, extra=120):
+    rng = np.random.default_rng(0)
+    return np.unique(np.r_[0, 1, 255, 256, 257, B // 2 - 1, B // 2, B - 2, B - 1, rng.integers(0, B, extra)])
+
+
+def test_neural2d_65536_rows_match_oracle(gpu_device, oracle_mod):
+    """BASELINE config 3 at its FULL batch: rows sampled from the 65536-codeword decode equal the oracle's single-codeword
+    results (bits, iterations, success exact; posterior within 1e-5), both stop modes, every engine form"""
+    import codes
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    B = 65536
+    code = codes.load_code("ira_1998_1512", 10)
+    g = code.tanner_graph()
+    dec = Neural2DMinSumDecoder(code, 2, 10)
+    rng = np.random.default_rng(4321)                           # bench.py's synthetic "pretrained" tables
+    with torch.no_grad():
+        for k in sorted(dec.beta_weights.keys()):
+            dec.beta_weights[k].fill_(float(np.float32(rng.uniform(0.5, 1.0))))
+        for k in sorted(dec.alpha_weights.keys()):
+            dec.alpha_weights[k].fill_(float(np.float32(rng.uniform(0.8, 1.2))))
+    beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+    alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+    eng = dec._get_engine(gpu_device)
+    llr = torch.cat([awgn_gpu(B // 2, g.n, 2.0, 21, gpu_device), awgn_gpu(B // 2, g.n, 4.5, 22, gpu_device)])
+    llr = llr[torch.randperm(B, device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(23))]
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    rows = _oracle_rows(B)
+    x = llr[rows].detach().cpu().numpy()
+    for early in (True, False):
+        res = eng.decode(llr, early_stop=early)
+        ob, op, oi, os_ = oracle_mod.neural2d(og, x, 2, 10, beta, alpha, early_stop=early)
+        np.testing.assert_array_equal(res.bits[rows].cpu().numpy(), ob)
+        np.testing.assert_array_equal(res.iterations[rows].cpu().numpy(), oi)
+        np.testing.assert_array_equal(res.success[rows].cpu().numpy(), os_)
+        np.testing.assert_allclose(res.posterior[rows].cpu().numpy(), op, rtol=1e-5, atol=1e-5)
+        if early:
+            assert len(np.unique(oi)) >= 3                       # the sample spans stopped and unstopped codewords
+        np.testing.assert_array_equal(res.success.cpu().numpy(), syndrome_ok(g, res.bits))
+
+
+def test_rcq_65536_rows_match_oracle_with_edge_codes(gpu_device, oracle_mod, engine_mode):
+    """BASELINE config 4 at its FULL batch: sampled rows equal the oracle bit for bit -- bits, iterations, success, and
+    the 3-bit quantiser code of EVERY edge in the last executed iteration (CSR order) -- both stop modes, every engine form"""
+    import codes
+    from rcq_decoder import RCQMinSumDecoder, _quantizer_schedule, _threshold_table
+    B = 65536
+    code = codes.load_code("ira_1998_1512", 10)
+    g = code.tanner_graph()
+    dec = RCQMinSumDecoder(code, 3, 8, QP, 10)
+    eng = dec._get_engine(gpu_device)
+    llr = torch.cat([awgn_gpu(B // 2, g.n, 2.0, 31, gpu_device), awgn_gpu(B // 2, g.n, 5.0, 32, gpu_device)])
+    llr = llr[torch.randperm(B, device=gpu_device, generator=torch.Generator(device=gpu_device).manual_seed(33))]
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    rows = _oracle_rows(B)
+    x = llr[rows].detach().cpu().numpy()
+    thr = _threshold_table(dec.quantizers)
+    q_of_iter = _quantizer_schedule(len(dec.quantizers), 10)
+    L = thr.shape[1]
+    for early in (True, False):
+        res = eng.decode(llr, early_stop=early)
+        ob, _, oi, os_, ocodes = oracle_mod.rcq(og, x, 3, QP, 10, early_stop=early, trace_codes=True)
+        np.testing.assert_array_equal(res.bits[rows].cpu().numpy(), ob)
+        np.testing.assert_array_equal(res.iterations[rows].cpu().numpy(), oi)
+        np.testing.assert_array_equal(res.success[rows].cpu().numpy(), os_)
+        want = np.stack([ocodes[r, int(oi[r]) - 1] for r in range(len(rows))])     # codes of the last executed iteration
+        if eng.info()["engine"] == "stream":
+            got = eng.debug_c2v(B)[torch.from_numpy(rows).to(gpu_device)].cpu().numpy()
+            np.testing.assert_array_equal(got, want)
+        else:
+            # resident engine: reconstructed values out of LDS -> codes (sign bit of a zero tells code L from code 0; the
+            # reference gives code 0 to w = -0.0, the value read-out sees -0.0 as code L: both reconstruct to zero)
+            vals, _, it2 = eng.debug_resident_c2v(llr[torch.from_numpy(rows).to(gpu_device)], early_stop=early)
+            vals, it2 = vals.cpu().numpy(), it2.cpu().numpy()
+            np.testing.assert_array_equal(it2, oi)
+            for r in range(len(rows)):
+                tau = thr[q_of_iter[int(oi[r]) - 1]]
+                level = np.searchsorted(tau, np.abs(vals[r]))
+                assert np.all(level < L) and np.array_equal(tau[level], np.abs(vals[r])), "not a reconstruction level"
+                got = np.where(np.signbit(vals[r]), L, 0) + level
+                bad = got != want[r]
+                assert not np.any(bad & ~((want[r] == 0) & (got == L)))
+        assert res.success.cpu().numpy().sum() > 0 or not early
+
+
 def test_dvbs2_wrcq_32768_properties(gpu_device, oracle_mod):
     """config 5's per-GPU shard: (16200,7200), W-RCQ type 2, T=20, 32768 codewords"""
     import codes
@@ -228,15 +312,46 @@ def test_bench_default_run_carries_every_baseline_config(gpu_device):
 
 @pytest.mark.parametrize("engine_mode", ["auto"], indirect=True)
 def test_bench_bare_multi_rank_launch(gpu_device):
-    """`python bench.py --gpus N` started bare spawns its own ranks (children created before any GPU call): a 2-rank
-    gloo rehearsal on this one GPU and a 1-rank RCCL run each give exactly one JSON line with the right n_gpus"""
-    d = run_bench(["--gpus", "2", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-stream-leg"],
+    """`python bench.py --gpus N` started bare spawns its own ranks (children created before any GPU call).  A 2-rank
+    gloo rehearsal on this one GPU and a 1-rank RCCL run each give exactly one JSON line that carries everything the
+    north_star asks of a multi-GPU run: the rank count the process group reports, every rank's device, the all-gather
+    timed alone, the content check of the gathered array, config 5 sharded weak and strong, and the CPU baseline."""
+    d = run_bench(["--gpus", "2", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-stream-leg", "--no-legs"],
                   {"LDPC_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16384 and d["scaling"] == "weak"
     assert "all_gather" in d["config"]["collective"]
+    dd = d["distributed"]
+    assert dd["world_size"] == 2 and dd["backend"] == "gloo" and [r["rank"] for r in dd["ranks"]] == [0, 1]
+    assert all("device_index" in r and "name" in r for r in dd["ranks"])
+    assert dd["gather_check"]["ok"] and dd["gather_check"]["own_shard_equal_on_ranks"] == 2
+    assert dd["gather_check"]["sum_of_shard_checksums"] == dd["gather_check"]["checksum_of_gathered"] > 0
+    ga = dd["allgather"]
+    assert ga["ms"] > 0 and ga["bytes_per_rank"] == 8192 * ((1998 + 7) // 8) and ga["bytes_gathered"] == 2 * ga["bytes_per_rank"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"     # rank 0's host cores, also at N > 1
+    assert d["roofline"]["bound"] == "lds"
+    # the DEFAULT multi-rank line (no --batch / --workload): config 2 weak + config 5 sharded weak and strong in the same line
+    d = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--leg-steps", "1", "--no-stream-leg", "--no-cpu-baseline",
+                   "--config5-total", "4096", "--sweep-reps", "2"], {"LDPC_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert d["n_gpus"] == 2 and d["config"]["batch_per_gpu"] == 65536
+    sw = d["sharded_workloads"]
+    weak, strong = sw["wrcq_dvbs2_weak"], sw["wrcq_dvbs2_strong"]
+    assert weak["scaling"] == "weak" and weak["batch_per_gpu"] == 32768 and weak["global_batch"] == 65536
+    assert strong["scaling"] == "strong" and strong["batch_per_gpu"] == 2048 and strong["global_batch"] == 4096
+    for leg in (weak, strong):
+        assert leg["value"] > 0 and leg["gather_check"]["ok"] and leg["allgather"]["ms"] > 0
+        assert leg["engine"]["engine"] == "stream"
+        assert leg["allgather"]["bytes_per_rank"] == leg["batch_per_gpu"] * ((16200 + 7) // 8)
     d = run_bench(["--gpus", "2", "--workload", "wrcq_dvbs2", "--strong", "--batch", "2048", "--steps", "1", "--warmup", "1"],
                   {"LDPC_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 1024
+    assert d["distributed"]["gather_check"]["ok"]
+    # one rank over RCCL (backend "nccl"): the collective really is RCCL's, overlapped and un-overlapped
     d = run_bench(["--gpus", "1", "--force-dist", "--batch", "8192", "--steps", "2", "--warmup", "1", "--no-stream-leg",
-                   "--no-cpu-baseline"])
-    assert d["n_gpus"] == 1 and "nccl" in d["config"]["collective"]
+                   "--no-cpu-baseline", "--no-legs"])
+    assert d["n_gpus"] == 1 and "nccl" in d["config"]["collective"] and d["distributed"]["backend"] == "nccl"
+    assert d["distributed"]["world_size"] == 1 and d["distributed"]["gather_check"]["ok"]
+    assert d["distributed"]["allgather"]["ms"] > 0 and d["config"]["overlap"] is True
+    d = run_bench(["--gpus", "1", "--force-dist", "--no-overlap", "--steps", "1", "--warmup", "1", "--leg-steps", "1",
+                   "--no-stream-leg", "--no-cpu-baseline", "--config5-total", "2048", "--sweep-reps", "2"])
+    assert d["config"]["overlap"] is False and d["sharded_workloads"]["wrcq_dvbs2_strong"]["batch_per_gpu"] == 2048
+    assert d["sharded_workloads"]["wrcq_dvbs2_weak"]["gather_check"]["ok"]

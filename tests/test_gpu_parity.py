@@ -603,6 +603,82 @@ def test_layered_paper_schedule_vs_cpu_restatement(early_stop, gpu_device, oracl
     assert it_lay < it_flo
 
 
+def _layered_case_code(rng, n, m, dc_lo, dc_hi, deg1=False):
+    """random code whose check degrees lie in [dc_lo, dc_hi] (deg1: check 0 has one edge)"""
+    from ldpc_decoder import LDPCCode
+    H = np.zeros((m, n), dtype=np.int64)
+    for i in range(m):
+        dc = 1 if (deg1 and i == 0) else int(rng.integers(dc_lo, dc_hi + 1))
+        H[i, rng.choice(n, size=dc, replace=False)] = 1
+    return LDPCCode(n=n, k=max(n - m, 1), H=H, max_iterations=6)     # some variables may be in no check at all
+
+
+@pytest.mark.parametrize("case", ["lw1", "lw2", "lw4", "lw8", "lw16", "lw32", "lw64", "deg1", "gamma0", "bc4", "bc5", "bign"])
+def test_layered_lds_kernel_every_lane_width_vs_oracle_and_streaming_kernel(case, gpu_device, oracle_mod, engine_mode):
+    """RCQMinSumDecoder(layered=True) on the LDS-resident kernel (lanes over the edges of a check, ldpc_layered.hip): every
+    lane width 1..64, a degree-1 check, a quantiser whose zero level is not zero (gamma = 0: general sign rule), 8 and 16
+    levels, a code whose posteriors leave room for fewer codewords per wave than lane groups, ragged batches, both stop
+    modes, packed bits -- against the oracle's restatement of rcq_decoder.py:281-350 and, bit for bit, against the
+    streaming kernel (engine modes other than auto run that one)."""
+    from rcq_decoder import RCQMinSumDecoder
+    rng = np.random.default_rng(sum(map(ord, case)))
+    qp, bc, T = QP, 3, 6
+    if case.startswith("lw"):
+        lw = int(case[2:])
+        lo, hi = (1, 1) if lw == 1 else (lw // 2 + 1, lw)
+        code = _layered_case_code(rng, 90 if lw < 64 else 130, 30, lo, hi)
+    elif case == "deg1":
+        code = _layered_case_code(rng, 80, 28, 3, 7, deg1=True)
+    elif case == "gamma0":
+        code, qp = _layered_case_code(rng, 80, 28, 3, 8), [(1.5, 0.0), (3.0, 1.3), (2.0, 0.0)]
+    elif case == "bc4":
+        code, bc = _layered_case_code(rng, 80, 28, 3, 8), 4
+    elif case == "bc5":
+        code, bc = _layered_case_code(rng, 80, 28, 3, 8), 5
+    else:                                                       # 4n bytes per codeword: only 2 of the 8 lane groups hold one
+        code = _layered_case_code(rng, 16000, 40, 5, 8)
+    tg = code.tanner_graph()
+    og = oracle_mod.OracleGraph(n=tg.n, check_ptr=tg.check_ptr, var_idx=tg.var_idx)
+    dec = RCQMinSumDecoder(code, bc, 8, qp, max_iterations=T, layered=True)
+    for B, snr in ((1, 3.0), (37, 2.0), (130, 5.0)):
+        llr = awgn(rng, B, tg.n, snr)
+        llr[0, :3] = 0.0                                         # exact zeros
+        if B > 2:
+            llr[1] = np.round(llr[1])                            # ties
+            llr[2] = np.abs(llr[2]) + 4.0                        # a codeword: stops after the first iteration
+        x = torch.from_numpy(llr).to(gpu_device)
+        eng = dec._get_engine(gpu_device)
+        if engine_mode == "auto":
+            assert eng.info()["engine"] == "resident" and eng.info()["threads_per_workgroup"] == 64
+        else:
+            assert eng.info()["engine"] == "stream"
+        ob, op, oi, os_ = oracle_mod.rcq_layered(og, llr, bc, qp, T)
+        res = eng.decode(x, early_stop=True, want_packed=True)
+        np.testing.assert_array_equal(res.iterations.cpu().numpy(), oi)
+        np.testing.assert_array_equal(res.success.cpu().numpy(), os_)
+        np.testing.assert_array_equal(res.bits.cpu().numpy(), ob)
+        np.testing.assert_array_equal(res.posterior.cpu().numpy(), op)
+        packed = res.packed_bits.cpu().numpy()
+        np.testing.assert_array_equal(((packed[:, :, None] >> np.arange(8)) & 1).reshape(B, -1)[:, :tg.n], ob)
+        fix = eng.decode(x, early_stop=False)
+        keep = ~os_                                              # never converged: the fixed-T walk is the same walk
+        assert np.all(fix.iterations.cpu().numpy() == T)
+        np.testing.assert_array_equal(fix.bits.cpu().numpy()[keep], ob[keep])
+        np.testing.assert_array_equal(fix.posterior.cpu().numpy()[keep], op[keep])
+        syn = (tg.syndrome(fix.bits.cpu().numpy()).any(axis=-1))
+        np.testing.assert_array_equal(fix.success.cpu().numpy(), ~syn)
+        if engine_mode == "auto":                                # bit for bit against the streaming kernel
+            eng.set_mode("stream")
+            try:
+                ref = eng.decode(x, early_stop=True)
+                ref_fix = eng.decode(x, early_stop=False)
+            finally:
+                eng.set_mode("auto")
+            for a_, b_ in ((res, ref), (fix, ref_fix)):
+                assert torch.equal(a_.bits, b_.bits) and torch.equal(a_.iterations, b_.iterations)
+                assert torch.equal(a_.success, b_.success) and torch.equal(a_.posterior, b_.posterior)
+
+
 def wide_check_code():
     """Checks far wider than a lane's slot row (degree 40, 64, 100, 33, 129) beside ordinary ones, variable degrees <= 8:
     the resident engine splits each wide check over a group of adjacent lanes (wavefront exchanges between the two

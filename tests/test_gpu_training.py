@@ -214,6 +214,31 @@ def test_stale_weights_are_restored_for_backward(gpu_device):
     assert torch.equal(post_b, post_b2)
 
 
+def test_backward_after_the_decoder_is_gone(gpu_device):
+    """the autograd node keeps its engine alive -- backward works after the decoder object (and with it the
+    only other reference to the engine) has been deleted, and after the decoder rebuilt its engine for another key"""
+    import gc
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    gold = load_golden("grad_toy")
+    sub = golden_sub(gold, "t2_T6")
+    T = 6
+    dec = Neural2DMinSumDecoder(make_code(gold, T), 2, T)
+    beta = weights_dict(sub["beta_keys"], sub["beta_vals"])
+    alpha = weights_dict(sub["alpha_keys"], sub["alpha_vals"])
+    sd = {f"beta_weights.{k}": torch.tensor([v]) for k, v in beta.items()}
+    sd.update({f"alpha_weights.{k}": torch.tensor([v]) for k, v in alpha.items()})
+    dec.load_state_dict(sd)
+    llr = torch.from_numpy(sub["llr"]).to(gpu_device)
+    _, post, _ = dec(llr)
+    betas, alphas = dict(dec.beta_weights.items()), dict(dec.alpha_weights.items())     # the leaves outlive the module
+    dec._engine = None                                  # what a device / max_iterations change does: the engine is rebuilt
+    del dec
+    gc.collect()
+    codeword_loss_sum(post).backward()
+    assert_grads(param_grads(betas), weights_dict(sub["grad_beta_keys"], sub["grad_beta_vals"]), "beta")
+    assert_grads(param_grads(alphas), weights_dict(sub["grad_alpha_keys"], sub["grad_alpha_vals"]), "alpha")
+
+
 def test_forms_without_a_gradient_path(gpu_device):
     """RCQ: the reference's quantiser passes no gradient either (posterior without grad_fn); the native call says so"""
     from ldpc_decoder import create_test_ldpc_code

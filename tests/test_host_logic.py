@@ -338,3 +338,83 @@ def test_reference_import_lines_work_verbatim():
     assert list(a.beta_weights.keys()) == list(b.beta_weights.keys()) and len(a.beta_weights) == 2 * 13
     for k in a.beta_weights.keys():
         assert b.beta_weights[k].item() == pytest.approx(a.beta_weights[k].item() + 0.7, abs=1e-6)
+
+
+def test_native_library_staleness_is_decided_by_content_hash(tmp_path, monkeypatch):
+    """file times say nothing after a copy to another box.  build_native / load decide by a hash of the
+    sources' CONTENT (plus the compile recipe) stored beside the library; a library without a matching record is stale
+    and is never loaded silently."""
+    import _native
+    lib_path = os.path.join(PKG, "libldpc_hip.so")
+    assert os.path.exists(lib_path), "run __graft_entry__.build() first"
+    assert _native.built_hash(lib_path) == _native.source_hash() and not _native.is_stale(lib_path)
+    # touching a source (newer mtime, same content) does not make the library stale ...
+    src = os.path.join(PKG, "csrc", "ldpc_train.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, (st.st_atime + 1e6, st.st_mtime + 1e6))
+        assert not _native.is_stale(lib_path)
+        assert _native.build_native(force=False) == lib_path            # returns at once: no hipcc run
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    # ... a different recipe or different content does
+    assert _native.source_hash(defines=("LDPC_X=1",)) != _native.source_hash()
+    fake = tmp_path / "libldpc_hip.so"
+    fake.write_bytes(b"not a library")
+    assert _native.is_stale(str(fake))                                   # no record beside it
+    (tmp_path / "libldpc_hip.so.srchash").write_text("0" * 64 + "\n")
+    assert _native.is_stale(str(fake))                                   # record of other sources
+    (tmp_path / "libldpc_hip.so.srchash").write_text(_native.source_hash() + "\n")
+    assert not _native.is_stale(str(fake))
+    # load() refuses a stale library loudly (no silent use, no compile inside an import)
+    (tmp_path / "libldpc_hip.so.srchash").write_text("0" * 64 + "\n")
+    monkeypatch.setattr(_native, "LIB_PATH", str(fake))
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.delenv("LDPC_HIP_LIB", raising=False)
+    with pytest.raises(_native.NativeEngineError, match="stale"):
+        _native.load()
+
+
+def test_native_graph_cache_holds_graphs_weakly():
+    """one device graph per (TannerGraph, device) while the host graph lives; entries go when it dies (no GPU needed:
+    the factory is injected)"""
+    import gc
+    from engine import _NativeGraph
+    from tanner_graph import TannerGraph
+    made = []
+
+    class Fake:
+        def __init__(self, tag):
+            made.append(tag)
+
+    before = len(_NativeGraph._cache)
+    g1 = TannerGraph.from_dense(np.array([[1, 1, 0], [0, 1, 1]]))
+    g2 = TannerGraph.from_dense(np.array([[1, 1, 0], [0, 1, 1]]))
+    a = _NativeGraph._get(g1, 0, lambda: Fake("g1/0"))
+    assert _NativeGraph._get(g1, 0, lambda: Fake("again")) is a and made == ["g1/0"]
+    b = _NativeGraph._get(g1, 1, lambda: Fake("g1/1"))
+    c = _NativeGraph._get(g2, 0, lambda: Fake("g2/0"))                 # equal content, different object: its own entry
+    assert b is not a and c is not a and len(_NativeGraph._cache) == before + 3
+    del g1
+    gc.collect()
+    assert len(_NativeGraph._cache) == before + 1                      # both device entries of g1 evicted
+    del g2
+    gc.collect()
+    assert len(_NativeGraph._cache) == before
+
+
+def test_bench_bare_launch_reports_a_failing_rank_at_once():
+    """`python bench.py --gpus 2` on a box without a GPU: every rank fails at start-up; the parent polls all children,
+    exits non-zero within seconds (no waiting in a collective) and shows each rank's stderr"""
+    import subprocess
+    import sys
+    import time
+    if torch.cuda.is_available():
+        pytest.skip("checks the no-GPU behaviour")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "rank 0 stderr" in out.stderr and "rank 1 stderr" in out.stderr and "no CPU fallback" in out.stderr
+    assert time.time() - t0 < 120

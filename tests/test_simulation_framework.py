@@ -108,3 +108,61 @@ def test_simulator_counters_match_direct_decode(gpu_device, tmp_path):
     assert set(res) == {"Basic", "RCQ"} and len(res["Basic"].frame_error_rates) == 2
     assert res["Basic"].frame_error_rates[1] <= res["Basic"].frame_error_rates[0]
     assert (tmp_path / "simulation_results.json").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["basic", "rcq", "neural2d"])
+def test_simulator_counters_match_oracle_decoded_blocks(family, gpu_device, oracle_mod, tmp_path):
+    """SURVEY 8f-1 against the ORACLE: the blocks the simulator draws are decoded frame by frame on the CPU by the
+    restatement of the reference's decoders, the reference's own per-frame loop (simulation_framework.py:110-132: errors,
+    bit errors of erroneous frames, iterations, stop at max_frames / max_errors) is applied to those outcomes, and
+    FER / BER / average iterations / frame and error counts must equal what LDPSimulator.simulate_single_snr returns."""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder
+    from simulation_framework import LDPSimulator, SimulationConfig
+    qp = [(3.0, 1.3), (5.0, 1.3), (7.0, 1.3)]
+    code = codes.load_code("small_96_48", 10)
+    g = code.tanner_graph()
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    if family == "basic":
+        dec = BasicMinSumDecoder(code, 0.7)
+        cpu = lambda x: oracle_mod.basic_minsum(og, x, 0.7, 10, dtype=np.float32)
+    elif family == "rcq":
+        dec = RCQMinSumDecoder(code, 3, 8, qp, 10)
+        cpu = lambda x: oracle_mod.rcq(og, x, 3, qp, 10)
+    else:
+        dec = Neural2DMinSumDecoder(code, 2, 10)
+        rng = np.random.default_rng(7)
+        with torch.no_grad():
+            for k in sorted(dec.beta_weights.keys()):
+                dec.beta_weights[k].fill_(float(np.float32(rng.uniform(0.5, 1.0))))
+            for k in sorted(dec.alpha_weights.keys()):
+                dec.alpha_weights[k].fill_(float(np.float32(rng.uniform(0.8, 1.2))))
+        beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+        alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+        cpu = lambda x: oracle_mod.neural2d(og, x, 2, 10, beta, alpha)
+    for snr_db, max_frames, max_errors, block in ((3.0, 2500, 30, 384), (1.0, 700, 1000, 200), (5.0, 1500, 5, 512)):
+        cfg = SimulationConfig(max_frames=max_frames, max_errors=max_errors, batch_frames=block, seed=9,
+                               results_dir=str(tmp_path), save_results=False)
+        sim = LDPSimulator(cfg)
+        with torch.no_grad():
+            fer, ber, avg_it, _t, frames, errs = sim.simulate_single_snr(dec, code, snr_db, max_frames, max_errors)
+        # the same blocks (same generator seed and draw sizes), decoded by the oracle; then the reference's loop, frame by frame
+        gen = torch.Generator(device=gpu_device)
+        gen.manual_seed(9 * 1_000_003 + int(round(snr_db * 1000)))
+        total = frame_errors = bit_errors = total_iterations = 0
+        while total < max_frames and frame_errors < max_errors:
+            x = sim._draw_llr(gen, min(block, max_frames - total), code.n, snr_db, gpu_device).cpu().numpy()
+            ob, _, oi, _ = cpu(x)[:4]
+            for r in range(len(x)):                              # simulation_framework.py:110-132
+                if not (total < max_frames and frame_errors < max_errors):
+                    break
+                if ob[r].any():                                  # all-zero codeword was sent
+                    frame_errors += 1
+                    bit_errors += int(ob[r].sum())
+                total_iterations += int(oi[r])
+                total += 1
+        assert (frames, errs) == (total, frame_errors)
+        assert fer == frame_errors / total and ber == bit_errors / (total * code.n) and avg_it == total_iterations / total
