@@ -56,8 +56,10 @@ WORKLOADS = {
     "rcq": ("ira_1998_1512", 10, 65536, "f32", "(1998,1512) IRA code, RCQMinSumDecoder bc=3 bv=8, 3 quantisers"),
     "wrcq_dvbs2": ("dvbs2_like_16200_7200", 20, 32768, "f32", "(16200,7200) DVB-S2-like code, WeightedRCQDecoder type 2 bc=3"),
     "basic_f64": ("ira_1998_1512", 10, 65536, "f64", "(1998,1512) IRA code, BasicMinSumDecoder factor=0.7, float64 as in the reference"),
+    "rcq_layered": ("ira_1998_1512", 10, 65536, "f32", "(1998,1512) IRA code, RCQMinSumDecoder bc=3 layered=True (the reference's "
+                                                       "layered schedule as it executes, rcq_decoder.py:281-350)"),
 }
-LEGS = ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64")       # secondary legs of the default single-GPU run
+LEGS = ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64", "rcq_layered")   # secondary legs of the default single-GPU run
 
 
 def parse_args(argv=None):
@@ -168,8 +170,8 @@ def build_decoder(workload, device):
         dec = Neural2DMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
         synthetic_tables(dec)
         eng = dec._get_engine(device)
-    elif workload == "rcq":
-        dec = RCQMinSumDecoder(code, bc=3, bv=8, quantizer_params=QP, max_iterations=T)
+    elif workload in ("rcq", "rcq_layered"):
+        dec = RCQMinSumDecoder(code, bc=3, bv=8, quantizer_params=QP, max_iterations=T, layered=workload == "rcq_layered")
         eng = dec._get_engine(device)
     else:
         dec = WeightedRCQDecoder(code, bc=3, bv=8, quantizer_params=QP, weight_sharing_type=2, max_iterations=T)
@@ -196,7 +198,7 @@ def wants_posterior(workload):
 def byte_model(workload, g, T, B):
     """SURVEY 8d ALGORITHMIC bytes (reference formulation: messages through HBM once per sweep)"""
     es = 8 if workload == "basic_f64" else 4
-    rcq_like = workload in ("rcq", "wrcq_dvbs2")
+    rcq_like = workload in ("rcq", "wrcq_dvbs2", "rcq_layered")
     c2v = 1 if rcq_like else es
     per_iter = 2 * (es + c2v) * g.E + es * g.n                    # fp32: 16E + 4n, RCQ: 10E + 4n
     return {"decode": (T * per_iter + (es + 4) * g.n) * B,        # + posterior and int32 decisions out
@@ -229,6 +231,36 @@ def load_traffic(workload):
         return {**db.get(workload + "_gather", {}), **db.get(workload, {})}     # `_gather`: the pass with that RCQ form forced
     except Exception:
         return {}
+
+
+SIMDS, CUS, CLOCK_HZ = 1024, 256, 2.4e9            # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+
+def issue_limits(workload, kernel, B, ms):
+    """Instruction-issue and LDS-pipe time of a kernel from the SQ counters of the latest profiled build
+    (profiles/counters.json, written by tools/summarize_counters.py; per-launch averages at the workload's default batch):
+      valu_issue: SQ_INSTS_VALU wave-instructions x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for 4 cycles)
+                  / 1024 SIMDs / 2.4 GHz -- the time the VALUs alone need;
+      lds_pipe  : SQ_LDS_IDX_ACTIVE cycles (LDS array busy, bank-conflict replays included) / 256 CUs / 2.4 GHz.
+    `frac` = that time / the measured launch time; the larger one is the binding limit.  None when no counters are on file
+    for this batch."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))[workload][kernel]
+    except Exception:
+        return None
+    if B != WORKLOADS[workload][2] or "SQ_INSTS_VALU" not in ent:
+        return None
+    out = {"source": ent.get("source"), "clock_GHz": CLOCK_HZ / 1e9}
+    valu_ms = ent["SQ_INSTS_VALU"] * 4 / SIMDS / CLOCK_HZ * 1e3
+    out["valu_issue"] = {"wave_instructions_per_launch": ent["SQ_INSTS_VALU"], "ms": valu_ms, "frac": valu_ms / ms}
+    if "SQ_LDS_IDX_ACTIVE" in ent:
+        lds_ms = ent["SQ_LDS_IDX_ACTIVE"] / CUS / CLOCK_HZ * 1e3
+        out["lds_pipe"] = {"busy_cycles_per_launch": ent["SQ_LDS_IDX_ACTIVE"], "ms": lds_ms, "frac": lds_ms / ms,
+                           "bank_conflict_share": (ent.get("SQ_LDS_BANK_CONFLICT", 0.0) / ent["SQ_LDS_IDX_ACTIVE"])
+                           if ent["SQ_LDS_IDX_ACTIVE"] else None}
+    best = max((k for k in ("valu_issue", "lds_pipe") if k in out), key=lambda k: out[k]["frac"])
+    out["binding"] = best
+    return out
 
 
 def traffic_of(db, kernel, workload=None, B=None):
@@ -343,6 +375,8 @@ def resident_roofline(eng, workload, g, T, B, ms, copy_gbs):
     lds_ach = (reads + writes) / (ms * 1e-3) / 1e9
     return {"bound": "lds", "kernel": "ldpc::resident_decode (fused T-iteration decode, messages resident in LDS)",
             "achieved": lds_ach, "peak": lds_ach * ms / t_min, "unit": "GB/s", "frac": t_min / ms,
+            # what actually binds the kernel: VALU issue and the LDS pipe's busy time (conflict replays included), from counters
+            "issue_limits": issue_limits(workload, "resident_decode", B, ms),
             "ms_per_launch": ms, "lds_read_bytes": reads, "lds_write_bytes": writes, "lds_min_ms": t_min,
             "traffic": tr, "traffic_source": src,
             "hbm": {"bytes_per_launch": hbm_bytes, "bytes_kind": "PMC-measured" if tr else "compulsory (LLRs in + decisions out)",
@@ -358,6 +392,30 @@ def resident_roofline(eng, workload, g, T, B, ms, copy_gbs):
             "note": "peak = the blended LDS rate of this read/write mix (ds_read_b64 256 B/clk/CU, ds_write_b64 ~85 B/clk/CU, "
                     "256 CUs, 2.4 GHz); the variable phase's gathers/scatters take ~2 LDS passes per instruction, the rest "
                     "is VALU issue and barriers"}
+
+
+def layered_roofline(eng, g, T, B, ms):
+    """The layered walk is ONE dependent chain of m*T check updates per codeword; the LDS-resident kernel (ldpc_layered.hip)
+    keeps `cw` codewords per one-wave workgroup and as many workgroups per CU as their posteriors fit 160 KiB of LDS.  What
+    bounds it is the latency of one step (LDS read -> cross-lane min/sign butterfly -> quantise -> LDS write) times the chain
+    length, times the rounds the batch needs at that residency -- reported as the achieved step time."""
+    info = eng.info()
+    if info["engine"] != "resident":
+        return {"bound": "latency", "kernel": "ldpc::layered_rcq (streaming form: posteriors in HBM, one wave per 64-codeword tile)",
+                "ms_per_launch": ms, "traffic": None}
+    cw, lds = max(info["codewords_per_workgroup"], 1), max(info["lds_bytes"], 1)
+    per_cu = max((160 * 1024) // lds, 1)
+    waves = (B + cw - 1) // cw
+    rounds = waves / (per_cu * CUS)
+    steps = g.m * T
+    step_ns = ms * 1e6 / max(rounds, 1.0) / max(steps, 1)
+    lds_bytes = 2.0 * 4 * g.E * T * B                                # one 4-byte read and write per edge and iteration
+    return {"bound": "latency", "kernel": "ldpc::layered_lds (layered RCQ walk, posteriors resident in LDS, lanes over the edges of a check)",
+            "ms_per_launch": ms, "codewords_per_wave": cw, "waves_per_cu": per_cu, "rounds": rounds, "dependent_steps": steps,
+            "achieved": step_ns, "unit": "ns per dependent check step", "cycles_per_step_at_2.4GHz": step_ns * 2.4,
+            "lds_traffic_GBps": lds_bytes / (ms * 1e-3) / 1e9, "traffic": None,
+            "note": "latency-bound by construction: codewords in flight per CU = LDS capacity / 4n bytes; no HBM or LDS "
+                    "bandwidth limit is near (HBM sees the LLRs in and the decisions out only)"}
 
 
 def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
@@ -385,6 +443,8 @@ def cpu_baseline(workload, dec, code, snr_db, budget_s=12.0):
                             {k: float(v.item()) for k, v in dec.alpha_weights.items()}, early_stop=False)
         elif workload == "rcq":
             oracle.rcq(og, x, 3, QP, T, early_stop=False)
+        elif workload == "rcq_layered":
+            oracle.rcq_layered(og, x, 3, QP, T)             # early-stop semantics only; at 2 dB nothing converges: T iterations
         else:
             oracle.weighted_rcq(og, x, 3, QP, 2, T, {k: float(v.item()) for k, v in dec.beta_weights.items()},
                                 {k: float(v.item()) for k, v in dec.alpha_weights.items()}, early_stop=False)
@@ -428,7 +488,9 @@ def measure_leg(workload, device, snr_db, steps, reps, copy_gbs, with_cpu, torch
            "dtype": dtype, "batch": B, "steps": steps, "ms_per_step": ms, "value": B / (ms * 1e-3), "unit": "codewords/s",
            "engine": eng.info(), "edges": g.E, "n": g.n,
            "decode_algorithmic_GBps": byte_model(workload, g, T, B)["decode"] / (ms * 1e-3) / 1e9}
-    if eng.info()["engine"] == "resident":
+    if workload == "rcq_layered":
+        leg["roofline"] = layered_roofline(eng, g, T, B, ms)
+    elif eng.info()["engine"] == "resident":
         leg["roofline"] = resident_roofline(eng, workload, g, T, B, ms, copy_gbs)
     else:
         leg["roofline"] = stream_roofline(eng, workload, g, T, B, llr, max(reps // 2, 2), copy_gbs, torch)

@@ -254,11 +254,46 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     return LDPC_OK;
 }
 
+// where the last variable pass may put the caller's rows itself (vn_last_rows) instead of a tile-major posterior array
+struct RowsOut {
+    float *posterior = nullptr;
+    int32_t *bits = nullptr;
+    long long batch = 0;
+    int qv = 4;                    // floats per store: 4 / 2 / 1
+};
+
+int allow_full_lds(const void *kfn, int device);
+
 template <typename T, int VEC>
 int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool use_done, hipStream_t s,
-              bool store_posterior = true)
+              bool store_posterior = true, const RowsOut *rows = nullptr)
 {
     const GraphDev g = d->g->dev();
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        if (rows && last) {
+            const int row = it < d->T ? it : 0;
+            const bool codes = d->form == LDPC_C2V_RCQ;
+            const int lut_stride = 2 * d->n_levels;
+            const int lut_total = codes ? d->n_quant * lut_stride : 0;
+            const int lut_cur = codes ? d->q_of_iter[row] * lut_stride : 0;
+            const size_t shmem = vn_rows_stage_bytes() + (size_t)lut_total * sizeof(float);
+            const int vb = (g.n + kRowsVars - 1) / kRowsVars;
+            const dim3 grid((unsigned)((size_t)w.tiles * vb)), block(kRowsThreads);
+            const uint64_t *done = use_done ? w.done : nullptr;
+#define LDPC_VR(CODES)                                                                                          \
+    do {                                                                                                        \
+        auto kfn = rows->qv == 4 ? vn_last_rows<CODES, 4> : rows->qv == 2 ? vn_last_rows<CODES, 2> : vn_last_rows<CODES, 1>; \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                              \
+        hipLaunchKernelGGL(kfn, grid, block, shmem, s, g, (const void *)w.c2v, (const float *)w.llrT,           \
+                           (const float *)d->lut, lut_total, lut_cur, lut_stride, (const int *)d->q_of_iter_dev, \
+                           (const int *)w.iters, w.bitsT, done, rows->posterior, rows->bits, rows->batch, vb);  \
+    } while (0)
+            if (codes) LDPC_VR(true); else LDPC_VR(false);
+#undef LDPC_VR
+            HIP_TRY(hipGetLastError());
+            return LDPC_OK;
+        }
+    }
     const int vb = (g.n + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid((unsigned)((size_t)w.tiles * vb)), block(kBlock);
     const int row = it < d->T ? it : 0;     // T == 0: posterior-only pass, alpha unused
@@ -459,14 +494,60 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     const int vc = (g.n + JT - 1) / JT;
     const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc));       // transposes: one block per (tile, 64-codeword run, chunk)
 
-    // 16-byte vector forms of the layout changes when rows and buffers allow
-    auto vec_ok = [&](const void *a, const void *b) {
-        return g.n % (16 / (int)sizeof(T)) == 0 && ((uintptr_t)a & 15u) == 0 && ((uintptr_t)b & 15u) == 0;
+    // vector forms of the layout changes: the caller side moves the widest of 16 / 8 / 4 bytes per lane that the row length
+    // and the buffers' alignment admit (0: not even element-aligned -- cannot happen for tensors, kept as the scalar kernels)
+    auto vec_bytes = [&](const void *a, const void *b) {
+        for (int vb = 16; vb >= (int)sizeof(T); vb >>= 1)
+            if (((size_t)g.n * sizeof(T)) % vb == 0 && ((uintptr_t)a & (vb - 1)) == 0 && ((uintptr_t)b & (vb - 1)) == 0) return vb;
+        return 0;
     };
-    if (vec_ok(llr, nullptr))
-        hipLaunchKernelGGL((transpose_in_v<T, VEC>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
-    else
-        hipLaunchKernelGGL((transpose_in<T, VEC>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+    auto layout_in = [&]() {
+        switch (vec_bytes(llr, nullptr)) {
+        case 16: hipLaunchKernelGGL((transpose_in_v<T, VEC, 16>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc); break;
+        case 8: hipLaunchKernelGGL((transpose_in_v<T, VEC, 8>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc); break;
+        case 4:
+            if constexpr (sizeof(T) == 4) {
+                hipLaunchKernelGGL((transpose_in_v<T, VEC, 4>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+                break;
+            }
+            [[fallthrough]];
+        default: hipLaunchKernelGGL((transpose_in<T, VEC>), tgrid, dim3(kBlock), 0, s, (const T *)llr, (T *)w.llrT, (long long)batch, g.n, vc);
+        }
+    };
+    auto layout_out = [&](const T *srcT) {
+        switch (vec_bytes(posterior, bits)) {
+        case 16: hipLaunchKernelGGL((transpose_out_v<T, VEC, 16>), tgrid, dim3(kBlock), 0, s, srcT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc); break;
+        case 8: hipLaunchKernelGGL((transpose_out_v<T, VEC, 8>), tgrid, dim3(kBlock), 0, s, srcT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc); break;
+        case 4:
+            if constexpr (sizeof(T) == 4) {
+                hipLaunchKernelGGL((transpose_out_v<T, VEC, 4>), tgrid, dim3(kBlock), 0, s, srcT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+                break;
+            }
+            [[fallthrough]];
+        default: hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s, srcT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
+        }
+    };
+    // code-pair form on 256-codeword tiles: the layout change also codes the LLRs for iteration 0 (transpose_in_q4)
+    bool fused_init = false;
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        if (use_pair(d) && !saved && pair_q4<VEC>(d) && T_it > 0 && d->schedule == LDPC_SCHED_FLOODING && vec_bytes(llr, nullptr) == 16) {
+            const int vb = (g.n + kRowsVars - 1) / kRowsVars;
+            const float *beta0 = (const float *)d->beta;
+            const float *thr0 = d->thresholds + (size_t)d->q_of_iter[0] * d->n_levels;
+#define LDPC_TIQ(NL_)                                                                                                \
+    do {                                                                                                             \
+        auto kfn = transpose_in_q4<NL_>;                                                                             \
+        if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                   \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)((size_t)w.tiles * vb)), dim3(kRowsThreads), vn_rows_stage_bytes(), s, g, \
+                           (const float *)llr, (float *)w.llrT, (uint8_t *)w.v2c, beta0, (const int *)d->beta_slot, \
+                           thr0, d->n_levels, (long long)batch, vb);                                                \
+    } while (0)
+            if (d->n_levels == 4) LDPC_TIQ(4); else LDPC_TIQ(0);
+#undef LDPC_TIQ
+            fused_init = true;
+        }
+    }
+    if (!fused_init) layout_in();
     {
         const long long cnt = (long long)w.tiles * W;
         hipLaunchKernelGGL((init_state<VEC>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, w.done,
@@ -488,14 +569,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                                    d->g->max_dc, (uint8_t *)nullptr);
             HIP_TRY(hipGetLastError());
             if (early_stop && T_it == 0) HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));
-            if (bits || posterior) {
-                if (vec_ok(posterior, bits))
-                    hipLaunchKernelGGL((transpose_out_v<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                                       (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
-                else
-                    hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                                       (const T *)w.llrT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
-            }
+            if (bits || posterior) layout_out((const T *)w.llrT);
             if (iterations || success || packed) {
                 long long threads = batch;
                 if (packed) threads = std::max<long long>(threads, std::min<long long>(batch * ((g.n + 7) / 8), 1ll << 22));
@@ -506,6 +580,17 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
             return LDPC_OK;
         } else {
             return fail(LDPC_ERR_UNSUPPORTED, "layered schedule is fp32 only");
+        }
+    }
+    // fp32, 256-codeword tiles, 16-byte-aligned caller rows: the last variable pass writes posterior / decisions into the
+    // caller's rows itself (vn_last_rows) -- no tile-major posterior array, no transpose_out pass
+    RowsOut rows_out;
+    const RowsOut *rows = nullptr;
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        if (!saved && T_it > 0 && (bits || posterior) && vec_bytes(posterior, bits) >= 4) {
+            rows_out.posterior = (float *)posterior; rows_out.bits = bits; rows_out.batch = (long long)batch;
+            rows_out.qv = vec_bytes(posterior, bits) / 4;
+            rows = &rows_out;
         }
     }
     if (T_it == 0) {
@@ -521,14 +606,14 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
             // check sweep on the LLRs) (vn_sweep_q quantises with the next iteration's beta and thresholds, cn_sweep_q is integer-only);
             // the last variable pass is the ordinary posterior pass over the C2V codes.
             const bool q4 = pair_q4<VEC>(d);      // LLRs -> V2C codes first, then iteration 0 is a code sweep like the others
-            if (q4 && T_it > 0) {
+            if (q4 && T_it > 0 && !fused_init) {
                 int rc = launch_vn_q<VEC>(d, w, -1, false, s);
                 if (rc) return rc;
             }
             for (int it = 0; it < T_it; ++it) {
                 int rc = (it == 0 && !q4) ? launch_cn<T, VEC>(d, w, 0, early_stop, s) : launch_cn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
-                rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s)
+                rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s, /*store_posterior=*/true, rows)
                                     : launch_vn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
                 if (early_stop)
@@ -555,7 +640,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                 if (early_stop || last) {
                     Workspace wv = w;
                     wv.c2v = buf[it & 1];
-                    rc = launch_vn<T, VEC>(d, wv, it, /*last=*/true, early_stop, s, /*store_posterior=*/last);
+                    rc = launch_vn<T, VEC>(d, wv, it, /*last=*/true, early_stop, s, /*store_posterior=*/last, last ? rows : nullptr);
                     if (rc) return rc;
                 }
                 if (early_stop)
@@ -580,7 +665,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         }
         int rc = launch_cn<T, VEC>(d, wc, it, early_stop, s);
         if (rc) return rc;
-        rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s);
+        rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s, /*store_posterior=*/true, rows);
         if (rc) return rc;
         if (early_stop) {
             hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
@@ -596,14 +681,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     }
     HIP_TRY(hipGetLastError());
 
-    if (bits || posterior) {
-        if (vec_ok(posterior, bits))
-            hipLaunchKernelGGL((transpose_out_v<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                               (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
-        else
-            hipLaunchKernelGGL((transpose_out<T, VEC>), tgrid, dim3(kBlock), 0, s,
-                               (const T *)w.postT, w.bitsT, (T *)posterior, bits, (long long)batch, g.n, vc);
-    }
+    if ((bits || posterior) && !rows) layout_out((const T *)w.postT);
     if (iterations || success || packed) {
         long long threads = batch;
         if (packed) threads = std::max<long long>(threads, std::min<long long>(batch * ((g.n + 7) / 8), 1ll << 22));

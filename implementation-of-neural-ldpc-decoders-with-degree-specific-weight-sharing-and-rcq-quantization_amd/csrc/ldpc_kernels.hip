@@ -802,6 +802,153 @@ __global__ __launch_bounds__(kBlock) void vn_sweep(GraphDev g, const void *__res
 }
 
 // ------------------------------------------------------------------------------------------
+// LAST variable pass that writes the CALLER's rows (fp32, 256-codeword tiles): posterior [B][n] and int32 decisions
+// [B][n] leave this kernel directly -- no tile-major posterior array, no transpose_out pass (on the (16200,7200) code
+// that pair moved 2.1 GB out and 2.1 GB back in and then wrote 4.2 GB at 3.2 TB/s).  One block = one tile x kRowsVars
+// consecutive variables: each wave forms the posteriors of its 16 variables exactly as vn_sweep<LAST> does (same
+// association order, same per-codeword LUT choice for latched codewords, same ballots), stages them in LDS as
+// s[row][variable] with row = c * 64 + lane (codeword 4 * lane + c of the tile) and a row stride of kRowsVars + 1 floats
+// -- conflict-free for the lanes' writes and for the 16 threads x 4 rows of a wave reading 16 bytes each -- and the
+// block then writes 256-byte runs of the callers' rows.
+// ------------------------------------------------------------------------------------------
+template <typename T, int BYTES> struct VecB { typedef T type __attribute__((ext_vector_type(BYTES / sizeof(T)))); };
+template <typename T> struct VecB<T, sizeof(T)> { typedef T type; };
+template <typename V, typename T> __device__ __forceinline__ T vec_get(const V &v, int q)
+{
+    if constexpr (sizeof(V) == sizeof(T)) return v; else return v[q];
+}
+template <typename V, typename T> __device__ __forceinline__ void vec_set(V &v, int q, T x)
+{
+    if constexpr (sizeof(V) == sizeof(T)) v = x; else v[q] = x;
+}
+
+constexpr int kRowsVars = 64;
+constexpr int kRowsStride = kRowsVars + 1;
+constexpr int kRowsThreads = 1024;   // 16 waves x 4 variables: the staging tile (66.5 KB) admits two blocks per CU, and the first
+                                     // phase needs every wave slot of the CU to keep enough row loads in flight (with 256-thread
+                                     // blocks -- 8 waves per CU -- the kernel ran at 3.7 TB/s)
+__host__ __device__ inline size_t vn_rows_stage_bytes() { return (size_t)256 * kRowsStride * sizeof(float); }
+
+template <typename T, int VEC, bool CODES, int ORDER, int DV>
+__device__ __forceinline__ Pack<T, VEC> vn_post_ct(const GraphDev &g, int tile, int j, int s0, int lane,
+                                                   const void *__restrict__ c2v, const T *__restrict__ llrT,
+                                                   const Lut<VEC> &lut)
+{
+    constexpr int W = kWave * VEC;
+    const size_t lane_off = (size_t)lane * VEC;
+    const size_t tileE = (size_t)tile * g.E;
+    int e[DV > 0 ? DV : 1];
+    Pack<T, VEC> x[DV > 0 ? DV : 1];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+#pragma unroll
+    for (int k = 0; k < DV; ++k) x[k] = load_c2v<T, VEC, CODES>(c2v, (tileE + e[k]) * W + lane_off, lut);
+    const Pack<T, VEC> l = ld<T, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+    Pack<T, VEC> post;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        T xs[DV > 0 ? DV : 1];
+#pragma unroll
+        for (int k = 0; k < DV; ++k) xs[k] = x[k].x[c];
+        post.x[c] = l.x[c] + sum_ct<DV, -1, ORDER, T>(xs);           // posterior: no alpha (:206-209)
+    }
+    return post;
+}
+
+// QV: floats per store on the caller side (4 / 2 / 1: what the row length and the buffers' alignment admit)
+template <bool CODES, int QV>
+__global__ __launch_bounds__(kRowsThreads, 8) void vn_last_rows(GraphDev g, const void *__restrict__ c2v,
+                                                       const float *__restrict__ llrT,
+                                                       const float *__restrict__ lut_global, int lut_total,
+                                                       int lut_cur_off, int lut_stride,
+                                                       const int *__restrict__ q_of_iter,
+                                                       const int *__restrict__ iters_ws,
+                                                       uint64_t *__restrict__ bitsT, const uint64_t *__restrict__ done,
+                                                       float *__restrict__ posterior, int *__restrict__ bits,
+                                                       long long batch, int var_blocks)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    constexpr int kPerWave = kRowsVars / (kRowsThreads / kWave);
+    extern __shared__ float rows_smem[];
+    float *stage = rows_smem;
+    float *lut_s = rows_smem + (size_t)W * kRowsStride;
+    if (CODES) {
+        for (int k = threadIdx.x; k < lut_total; k += kRowsThreads) lut_s[k] = lut_global[k];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int j0 = uni((blockIdx.x % var_blocks) * kRowsVars);
+
+    Frozen<VEC> fz;
+    load_frozen<VEC>(done, tile, lane, fz);
+    Lut<VEC> lut;
+    lut.base = lut_s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        lut.off[c] = lut_cur_off;
+        if (CODES && done && fz.one(c)) {
+            const int it = iters_ws[(size_t)tile * W + lane * VEC + c];      // 1-based stop iteration
+            lut.off[c] = q_of_iter[it > 0 ? it - 1 : 0] * lut_stride;
+        }
+    }
+    for (int u = 0; u < kPerWave; ++u) {
+        const int jj = wave * kPerWave + u, j = j0 + jj;
+        if (j >= g.n) break;                                        // wave-uniform
+        const int s0 = uni(g.var_ptr[j]);
+        const int dv = uni(g.var_ptr[j + 1]) - s0;
+        Pack<float, VEC> post;
+#define LDPC_VP_CASE(D) case D: post = vn_post_ct<float, VEC, CODES, 0, D>(g, tile, j, s0, lane, c2v, llrT, lut); break;
+        switch (dv) {
+            LDPC_VP_CASE(0) LDPC_VP_CASE(1) LDPC_VP_CASE(2) LDPC_VP_CASE(3) LDPC_VP_CASE(4)
+            LDPC_VP_CASE(5) LDPC_VP_CASE(6) LDPC_VP_CASE(7) LDPC_VP_CASE(8)
+        default: {
+            const size_t lane_off = (size_t)lane * VEC, tileE = (size_t)tile * g.E;
+            auto fetch = [&](int k) {
+                return load_c2v<float, VEC, CODES>(c2v, (tileE + g.csc_edge[s0 + k]) * W + lane_off, lut);
+            };
+            post = sum_rt<0, float, VEC>(dv, fetch);
+            const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) post.x[c] = l.x[c] + post.x[c];
+        }
+        }
+#undef LDPC_VP_CASE
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const uint64_t mask = __ballot(post.x[c] < 0.0f);        // the syndrome pass reads the ballot words
+            if (lane == 0) bitsT[((size_t)tile * g.n + j) * VEC + c] = mask;
+            stage[(size_t)(c * kWave + lane) * kRowsStride + jj] = post.x[c];
+        }
+    }
+    __syncthreads();
+    using FV = typename VecB<float, QV * 4>::type;
+    using IV = typename VecB<int, QV * 4>::type;
+    constexpr int kTpr = kRowsVars / QV;                            // threads per staged row
+    constexpr int kRpp = kRowsThreads / kTpr;                       // rows per pass (a wave: 64 / kTpr rows x kTpr threads,
+                                                                    //   banks (row + first float) mod 64 all distinct)
+    const int jq = (threadIdx.x % kTpr) * QV;
+    if (j0 + jq >= g.n) return;                                     // n is a multiple of QV (host check): whole vectors
+#pragma unroll 4
+    for (int p = 0; p < W / kRpp; ++p) {
+        const int r = p * kRpp + threadIdx.x / kTpr;                // staged row: codeword 4 * (r % 64) + r / 64 of the tile
+        const long long b = (long long)tile * W + (r & 63) * VEC + (r >> 6);
+        if (b >= batch) continue;
+        const float *src = stage + (size_t)r * kRowsStride + jq;
+        FV v;
+        IV d;
+#pragma unroll
+        for (int q = 0; q < QV; ++q) {
+            vec_set<FV, float>(v, q, src[q]);
+            vec_set<IV, int>(d, q, src[q] < 0.0f ? 1 : 0);
+        }
+        const size_t o = (size_t)b * g.n + j0 + jq;
+        if (posterior) __builtin_nontemporal_store(v, reinterpret_cast<FV *>(posterior + o));
+        if (bits) __builtin_nontemporal_store(d, reinterpret_cast<IV *>(bits + o));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // RCQ with ONE beta per check, "code pair" form: BOTH message directions travel as one byte per edge.
 //
 // The check update of iteration t+1 (rcq_decoder.py:242-246 / :559-563) sees a variable->check message v only through
@@ -1211,7 +1358,8 @@ template <int NL, bool ES, bool INIT, int DV>
 __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int off, int lane,
                                            const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
                                            uint8_t *__restrict__ v2c, float a, int ev, float bv,
-                                           const unsigned (&tb)[8], uint64_t *__restrict__ bitsT, const Frozen<4> &fz)
+                                           const unsigned (&tb)[8], uint64_t *__restrict__ bitsT, const Frozen<4> &fz,
+                                           const Pack<float, 4> *l_ext = nullptr)
 {
     constexpr int VEC = 4, W = kWave * VEC;
     constexpr int D = DV > 0 ? DV : 1;
@@ -1229,7 +1377,8 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
 #pragma unroll
     for (int k = 0; k < DV; ++k)
         q[k] = INIT ? 0u : __builtin_bit_cast(unsigned, ld<uint8_t, VEC>(c2v + (tileE + e[k]) * W + lane_off)) << 2;
-    const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
+    // l_ext: the LLRs come from the caller (transpose_in_q4 holds them in LDS), else from the tile-major array
+    const Pack<float, VEC> l = l_ext ? *l_ext : ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
 
     unsigned keys[D], sgns[D];
 #pragma unroll
@@ -1348,6 +1497,90 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
         default: break;
         }
 #undef LDPC_VQ_CASE
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout change + the code pair form's initial pass in ONE kernel (fp32, 256-codeword tiles, 16-byte-aligned caller rows):
+// caller rows llr[B][n] -> tile-major llrT[tile][n][256] AND the V2C codes of iteration 0 (every outgoing message is the LLR
+// itself, rcq_decoder.py:514-518, coded with iteration 0's beta and thresholds) -- the LLRs are in the block's LDS tile
+// anyway, so the separate vn_sweep_q4<INIT> pass (another read of the 4n-byte rows) disappears.
+// One block = one tile x kRowsVars variables, staged like vn_last_rows: s[row][variable], row = c * 64 + lane for codeword
+// 4 * lane + c, row stride kRowsVars + 1 floats.  Load: pass p covers the 64 codewords of one c (16 threads x 16 bytes per
+// codeword; a wave's four codewords have consecutive lanes -> 64 distinct banks per stored float).
+// ------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(kRowsThreads, 8) void transpose_in_q4(GraphDev g, const float *__restrict__ llr,
+                                                                   float *__restrict__ llrT, uint8_t *__restrict__ v2c,
+                                                                   const float *__restrict__ beta0,
+                                                                   const int *__restrict__ beta_slot,
+                                                                   const float *__restrict__ thr0, int n_levels,
+                                                                   long long batch, int var_blocks)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    constexpr int kWaves = kRowsThreads / kWave;
+    constexpr int kPerWave = kRowsVars / kWaves;                    // variables per wave (4)
+    constexpr int kTpr = kRowsVars / 4;                             // threads per codeword run (16 x 16 bytes)
+    constexpr int kRpp = kRowsThreads / kTpr;                       // codewords per pass (64)
+    static_assert(kRpp == kWave && W / kRpp == VEC, "one pass = the 64 codewords of one c");
+    extern __shared__ float rows_smem[];
+    float *stage = rows_smem;
+    typedef float F4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int tile = uni(blockIdx.x / var_blocks);
+    const int j0 = uni((blockIdx.x % var_blocks) * kRowsVars);
+    {
+        const int jq = (threadIdx.x % kTpr) * 4, l = threadIdx.x / kTpr;       // codeword 4 * l + c of the tile
+        F4 v[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const long long b = (long long)tile * W + l * VEC + c;
+            v[c] = (F4){1.0f, 1.0f, 1.0f, 1.0f};                    // padding codewords: benign positive LLR
+            if (b < batch && j0 + jq < g.n)
+                v[c] = __builtin_nontemporal_load(reinterpret_cast<const F4 *>(llr + (size_t)b * g.n + j0 + jq));
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float *dst = stage + (size_t)(c * kWave + l) * kRowsStride + jq;
+            dst[0] = v[c][0]; dst[1] = v[c][1]; dst[2] = v[c][2]; dst[3] = v[c][3];
+        }
+    }
+    __syncthreads();
+    const int jbase = j0 + wave * kPerWave;
+    if (jbase >= g.n) return;
+    unsigned tb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tb[q] = (q < n_levels) ? __float_as_uint(thr0[q]) : 0x7fc00000u;
+    // index data of the wave's variables, fetched once with the lanes in parallel (as vn_sweep_q4; <= 32 edges here)
+    const int nv = min(kPerWave, g.n - jbase);
+    const int vp = g.var_ptr[min(jbase + min(lane, kPerWave), g.n)];
+    const int s_base = __builtin_amdgcn_readfirstlane(vp);
+    const int n_edges = __builtin_amdgcn_readlane(vp, nv) - s_base;
+    int ev = 0;
+    float bv = 0.0f;
+    if (lane < n_edges) {
+        ev = g.csc_edge[s_base + lane];
+        bv = beta0[beta_slot[ev]];
+    }
+    Frozen<VEC> fz;
+    fz.bits = 0;
+#pragma unroll 1
+    for (int u = 0; u < nv; ++u) {
+        const int j = jbase + u, jj = j - j0;
+        const int s0 = __builtin_amdgcn_readlane(vp, u);
+        const int dv = __builtin_amdgcn_readlane(vp, u + 1) - s0;
+        Pack<float, VEC> l;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) l.x[c] = stage[(size_t)(c * kWave + lane) * kRowsStride + jj];
+        st<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + (size_t)lane * VEC, l);
+#define LDPC_TQ_CASE(D) \
+    case D: vn_q4_body<NL, false, true, D>(g, tile, j, s0 - s_base, lane, nullptr, nullptr, v2c, 0.0f, ev, bv, tb, nullptr, fz, &l); break;
+        switch (dv) {
+            LDPC_TQ_CASE(0) LDPC_TQ_CASE(1) LDPC_TQ_CASE(2) LDPC_TQ_CASE(3) LDPC_TQ_CASE(4)
+            LDPC_TQ_CASE(5) LDPC_TQ_CASE(6) LDPC_TQ_CASE(7) LDPC_TQ_CASE(8)
+        default: break;
+        }
+#undef LDPC_TQ_CASE
     }
 }
 
@@ -1966,22 +2199,24 @@ __global__ __launch_bounds__(kBlock) void transpose_out(const T *__restrict__ po
     }
 }
 
-// 16-byte-per-lane versions of the two layout changes (n a multiple of 16 / sizeof(T), 16-byte aligned caller buffers):
-// every thread issues its eight vector loads before the first use, so that a block keeps 32 KB in flight -- the scalar
-// kernels above have one or two 256-byte requests in flight per wave and run at half the sweep rate.
-template <typename T> struct Vec16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
-
-template <typename T, int VEC>
+// Vector versions of the two layout changes: every thread issues ALL its loads before the first use, so that a block
+// keeps 32 KB in flight -- the scalar kernels above have one or two 256-byte requests in flight per wave and run at half
+// the sweep rate.  The workspace side (tile rows) always moves 16 bytes per lane; the CALLER side moves VB bytes per lane,
+// the widest of 16 / 8 / 4 that the row length and the buffer alignment admit (n = 1998 floats: rows are 8-byte aligned,
+// VB = 8) -- a wave still touches 256 contiguous bytes of a codeword's row whatever VB is.
+template <typename T, int VEC, int VB>
 __global__ __launch_bounds__(kBlock) void transpose_in_v(const T *__restrict__ llr, T *__restrict__ llrT,
                                                          long long batch, int n, int var_chunks)
 {
     constexpr int W = kWave * VEC;
     constexpr int JT = transpose_vars<T>();
-    constexpr int VT = 16 / (int)sizeof(T);            // elements per 16-byte vector
-    constexpr int CV = JT / VT;                        // vectors per codeword run (32)
-    constexpr int WV = kWave / VT;                     // vectors per variable run
-    constexpr int PER = kWave * CV / kBlock;           // vectors per thread (8)
-    using V = typename Vec16<T>::type;
+    constexpr int VT = VB / (int)sizeof(T);            // elements per caller-side vector
+    constexpr int CV = JT / VT;                        // vectors per codeword run
+    constexpr int PER = kWave * CV / kBlock;           // caller-side vectors per thread
+    constexpr int WT = 16 / (int)sizeof(T);            // elements per workspace-side (16-byte) vector
+    constexpr int WV = kWave / WT;                     // vectors per variable run
+    using V = typename VecB<T, VB>::type;
+    using V16 = typename VecB<T, 16>::type;
     __shared__ T s[JT][kWave + 1];
     const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
     const int j0 = chunk * JT, w0 = sub * kWave;
@@ -1997,20 +2232,20 @@ __global__ __launch_bounds__(kBlock) void transpose_in_v(const T *__restrict__ l
     for (int k = 0; k < PER; ++k) {
         const int idx = threadIdx.x + k * kBlock, r = idx / CV, c = idx % CV;
 #pragma unroll
-        for (int q = 0; q < VT; ++q) s[c * VT + q][r] = v[k][q];
+        for (int q = 0; q < VT; ++q) s[c * VT + q][r] = vec_get<V, T>(v[k], q);
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < JT * WV / kBlock; ++k) {
         const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
-        V o;
+        V16 o;
 #pragma unroll
-        for (int q = 0; q < VT; ++q) o[q] = s[jj][wv * VT + q];
-        if (j0 + jj < n) *reinterpret_cast<V *>(llrT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * VT) = o;
+        for (int q = 0; q < WT; ++q) o[q] = s[jj][wv * WT + q];
+        if (j0 + jj < n) *reinterpret_cast<V16 *>(llrT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * WT) = o;
     }
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, int VB>
 __global__ __launch_bounds__(kBlock) void transpose_out_v(const T *__restrict__ postT,
                                                           const uint64_t *__restrict__ bitsT,
                                                           T *__restrict__ posterior, int *__restrict__ bits,
@@ -2018,48 +2253,50 @@ __global__ __launch_bounds__(kBlock) void transpose_out_v(const T *__restrict__ 
 {
     constexpr int W = kWave * VEC;
     constexpr int JT = transpose_vars<T>();
-    constexpr int VT = 16 / (int)sizeof(T);
+    constexpr int VT = VB / (int)sizeof(T);            // caller side
     constexpr int CV = JT / VT;
-    constexpr int WV = kWave / VT;
+    constexpr int WT = 16 / (int)sizeof(T);            // workspace side
+    constexpr int WV = kWave / WT;
     constexpr int PER = JT * WV / kBlock;
     constexpr int PB = kWave + 4;                      // byte row of the expanded hard decisions (rows stay 4-byte aligned)
-    using V = typename Vec16<T>::type;
-    typedef int IV __attribute__((ext_vector_type(VT)));
-    typedef uint8_t BV __attribute__((ext_vector_type(VT)));
+    using V = typename VecB<T, VB>::type;
+    using V16 = typename VecB<T, 16>::type;
+    using IV = typename VecB<int, VT * (int)sizeof(int)>::type;
+    typedef uint8_t BV __attribute__((ext_vector_type(WT)));
     __shared__ T s[JT][kWave + 1];
     __shared__ __align__(4) uint8_t pb[JT][PB];        // hard decision of (variable, codeword of this run), one byte each
     const int chunk = blockIdx.x % var_chunks, sub = (blockIdx.x / var_chunks) % VEC, tile = blockIdx.x / (var_chunks * VEC);
     const int j0 = chunk * JT, w0 = sub * kWave;
     if (posterior) {
-        V v[PER];
+        V16 v[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
             v[k] = (T)0;
-            if (j0 + jj < n) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(postT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * VT));
+            if (j0 + jj < n) v[k] = __builtin_nontemporal_load(reinterpret_cast<const V16 *>(postT + ((size_t)tile * n + j0 + jj) * W + w0 + wv * WT));
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
 #pragma unroll
-            for (int q = 0; q < VT; ++q) s[jj][wv * VT + q] = v[k][q];
+            for (int q = 0; q < WT; ++q) s[jj][wv * WT + q] = v[k][q];
         }
     }
     if (bits) {
-        // ballot words -> one byte per (variable, codeword): the thread that owns VT consecutive codewords of a variable
-        // reads the (at most VT) words holding them -- the 64 / VT threads of a variable read the same words, one request
+        // ballot words -> one byte per (variable, codeword): the thread that owns WT consecutive codewords of a variable
+        // reads the (at most WT) words holding them -- the 64 / WT threads of a variable read the same words, one request
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int idx = threadIdx.x + k * kBlock, jj = idx / WV, wv = idx % WV;
             BV o;
 #pragma unroll
-            for (int q = 0; q < VT; ++q) {
-                const int rw = w0 + wv * VT + q;        // codeword inside the tile: ballot lane rw / VEC, word rw % VEC
+            for (int q = 0; q < WT; ++q) {
+                const int rw = w0 + wv * WT + q;        // codeword inside the tile: ballot lane rw / VEC, word rw % VEC
                 const uint64_t word = (j0 + jj < n) ? bitsT[((size_t)tile * n + j0 + jj) * VEC + (rw % VEC)] : 0ull;
                 const unsigned half = (rw / VEC) < 32 ? (unsigned)word : (unsigned)(word >> 32);
                 o[q] = (uint8_t)((half >> ((rw / VEC) & 31)) & 1u);
             }
-            *reinterpret_cast<BV *>(&pb[jj][wv * VT]) = o;
+            *reinterpret_cast<BV *>(&pb[jj][wv * WT]) = o;
         }
     }
     __syncthreads();
@@ -2071,13 +2308,13 @@ __global__ __launch_bounds__(kBlock) void transpose_out_v(const T *__restrict__ 
             if (posterior) {
                 V o;
 #pragma unroll
-                for (int q = 0; q < VT; ++q) o[q] = s[c * VT + q][r];
+                for (int q = 0; q < VT; ++q) vec_set<V, T>(o, q, s[c * VT + q][r]);
                 __builtin_nontemporal_store(o, reinterpret_cast<V *>(posterior + (size_t)b * n + j0 + c * VT));
             }
             if (bits) {
                 IV o;
 #pragma unroll
-                for (int q = 0; q < VT; ++q) o[q] = (int)pb[c * VT + q][r];
+                for (int q = 0; q < VT; ++q) vec_set<IV, int>(o, q, (int)pb[c * VT + q][r]);
                 __builtin_nontemporal_store(o, reinterpret_cast<IV *>(bits + (size_t)b * n + j0 + c * VT));
             }
         }

@@ -111,10 +111,12 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
     const int n = pl.n, m = pl.m_pad, cw = pl.cw;                  // m: plan rows incl. the no-op padding
     const int row = lane / LW, t = lane % LW;
     const long long b0 = (long long)blockIdx.x * cw;
-    const bool row_live = row < cw && b0 + row < batch;             // this lane's codeword exists
-    // lane groups beyond the wave's codewords (cw < 64 / LW: large n) shadow the last one: same reads, same values written
+    // lane groups beyond the wave's codewords (cw < 64 / LW: large n) SHADOW the last one: same reads, same state, the same
+    // values written to the same addresses -- they must take every decision (frozen, latch) exactly as the group they shadow
+    const int row_eff = min(row, cw - 1);
+    const bool row_live = b0 + row_eff < batch;                     // this lane's codeword exists (padding rows of the last wave do not)
     const unsigned row_words = (unsigned)n + 1u;
-    const unsigned row_base = (unsigned)min(row, cw - 1) * row_words * 4u;
+    const unsigned row_base = (unsigned)row_eff * row_words * 4u;
 
     // LLRs: the caller's rows, coalesced (all 64 lanes over one row at a time); "posteriors = llr.clone()" (:288)
     for (int r = 0; r < cw; ++r) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
     unsigned ok;
     if (ES) ok = (row_live && frozen != 0u) ? 1u : 0u;
     else ok = syndrome() == 0u ? 1u : 0u;
-    if (row_live && t == 0) {
+    if (row_live && row < cw && t == 0) {
         if (iterations) iterations[b0 + row] = (ES && ok) ? my_iters : T;
         if (success) success[b0 + row] = (uint8_t)ok;
     }

@@ -17,11 +17,12 @@
 // summed over tiles and slots by reduce_table_grads in a fixed order: no atomics anywhere, the gradients are
 // bit-identical from run to run.
 //
-// Deviations from torch autograd on the reference's graph (documented, pinned by tests/test_gpu_training.py):
-//  * ties: when several edges of a check share the second-smallest magnitude, torch.min() of the masked vector
-//    (a full reduction) splits that gradient evenly among the tied elements; here it goes to the first tied
-//    edge.  Exact ties of non-zero fp32 magnitudes have probability ~0 on real LLRs; the golden gradients contain
-//    none, so parity on ties is unpinned.
+// Ties follow autograd too: `torch.min(temp_mags)` (neural_2d_decoder.py:179) is a full reduction whose backward splits
+// the gradient evenly among ALL elements that hold the minimum -- the second minimum's gradient is divided by the number
+// of edges tied for it (the set is tracked as a bit mask during the scan); `magnitudes[min_idx]` sends the minimum's to
+// the first arg-min edge.  Pinned by tests/golden/grad_ties.npz (the reference under autograd on half-integer LLRs).
+//
+// Deviation from torch autograd on the reference's graph (documented, pinned by tests/test_gpu_training.py):
 //  * parameters that cannot influence the returned posterior (iterations after every codeword stopped) receive a
 //    zero gradient where the reference leaves `.grad` None (an optimizer with momentum keeps moving those).
 #pragma once
@@ -110,12 +111,12 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
     auto in_row = [&](int u) { return FIRST ? in_base + (size_t)g.var_idx[e0 + u] * W : in_base + (size_t)u * W; };
 
     float m1[VEC], m2[VEC];
-    int idx[VEC], idx2[VEC];
-    uint32_t sm[VEC], zm[VEC];
+    int idx[VEC], k2[VEC];          // arg-min edge (first index); number of edges tied for the second minimum
+    uint32_t sm[VEC], zm[VEC], tm[VEC];   // sign bits, zero flags, and the edges tied for the second minimum (bit u & 31)
     unsigned par[VEC], nz[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-        m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); idx[c] = 0; idx2[c] = 0; sm[c] = 0; zm[c] = 0; par[c] = 0; nz[c] = 0;
+        m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); idx[c] = 0; k2[c] = 0; sm[c] = 0; zm[c] = 0; tm[c] = 0; par[c] = 0; nz[c] = 0;
     }
 #pragma unroll 4
     for (int u = 0; u < dc; ++u) {
@@ -127,13 +128,24 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
             const unsigned z = (a == 0.0f) ? 1u : 0u;
             par[c] ^= sb; nz[c] += z;
             sm[c] |= sb << (u & 31); zm[c] |= z << (u & 31);
-            if (a < m1[c]) { m2[c] = m1[c]; idx2[c] = idx[c]; m1[c] = a; idx[c] = u; }
-            else if (a < m2[c]) { m2[c] = a; idx2[c] = u; }
+            const uint32_t ub = 1u << (u & 31);
+            if (u == 0) {
+                m1[c] = a;                                                    // idx = 0; no second minimum yet (k2 == 0)
+            } else if (a < m1[c]) {
+                // the old minimum joins the second-minimum set: alone if it lies below the old second, else as one more tie
+                if (m1[c] < m2[c] || k2[c] == 0) { m2[c] = m1[c]; tm[c] = 1u << (idx[c] & 31); k2[c] = 1; }
+                else { tm[c] |= 1u << (idx[c] & 31); k2[c] += 1; }
+                m1[c] = a; idx[c] = u;
+            } else if (a < m2[c] || k2[c] == 0) {
+                m2[c] = a; tm[c] = ub; k2[c] = 1;
+            } else if (a == m2[c]) {
+                tm[c] |= ub; k2[c] += 1;
+            }
         }
     }
     if (dc == 1) {
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) { m2[c] = m1[c]; idx2[c] = idx[c]; }    // min2_val = min_val (:181-182)
+        for (int c = 0; c < VEC; ++c) { m2[c] = m1[c]; tm[c] = 1u; k2[c] = 1; }   // min2_val = min_val (:181-182): both to that edge
     }
     const bool wide = dc > 32;                     // the sign / zero masks hold 32 edges; wider checks re-read
 
@@ -190,7 +202,9 @@ __global__ __launch_bounds__(kBlock) void cn_backward(GraphDev g, const float *_
             const unsigned own = wide ? signbit_of<float>(re.x[c]) : ((sm[c] >> (u & 31)) & 1u);
             const unsigned ownz = wide ? ((re.x[c] == 0.0f) ? 1u : 0u) : ((zm[c] >> (u & 31)) & 1u);
             const float sg = ownz ? 0.0f : (own ? -1.0f : 1.0f);                           // d|x|/dx
-            const float gmag = ((u == idx[c]) ? acc1[c] : 0.0f) + ((u == idx2[c]) ? acc2[c] : 0.0f);
+            // member of the second-minimum set: the mask bit (<= 32 edges), else by value (the arg-min edge is not in it)
+            const bool tied = wide ? (u != idx[c] && __builtin_fabsf(re.x[c]) == m2[c]) : (((tm[c] >> (u & 31)) & 1u) != 0);
+            const float gmag = ((u == idx[c]) ? acc1[c] : 0.0f) + (tied ? acc2[c] / (float)k2[c] : 0.0f);
             o.x[c] = state[c] != 0 ? gmag * sg : 0.0f;
         }
         st<float, VEC>(out_base + (size_t)u * W, o);

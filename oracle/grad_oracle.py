@@ -9,6 +9,7 @@ What it restates: Neural2DMinSumDecoder.forward (neural_2d_decoder.py:133-225) a
 NeuralMinSumDecoder.forward -- the operations autograd differentiates there:
   magnitudes = |incoming|, signs = sign(incoming)                      (:170-171)
   min_val = magnitudes[argmin], min2_val = min(magnitudes with the arg-min set to inf); = min_val at dc == 1  (:174-182)
+      (gradient of min_val: the first arg-min edge; of min2_val: split evenly among the edges tied for it)
   c2v = beta * (min2_val | min_val) * prod(other signs)                (:186-191)
   v2c = llr + alpha * sum(other c2v)                                   (:203)
   posterior = llr + sum(c2v)                                           (:206-209), returned at the first zero syndrome
@@ -81,7 +82,10 @@ def forward(g, llr, beta_table, beta_slot, alpha_table, alpha_slot, T, early_sto
         signs = torch.where(cmask, torch.sign(inc), torch.ones((), dtype=dtype))
         m1, i1 = mags.min(dim=-1, keepdim=True)
         mags2 = mags.scatter(-1, i1, float("inf"))
-        m2 = mags2.min(dim=-1, keepdim=True).values
+        # torch.min(temp_mags) in the reference is a FULL reduction (neural_2d_decoder.py:179): its backward splits the
+        # gradient evenly among all elements that hold the minimum -- amin has exactly that rule (min(dim) would send
+        # it to one index); pinned by tests/golden/grad_ties.npz
+        m2 = mags2.amin(dim=-1, keepdim=True)
         m2 = torch.where((dc == 1).view(1, -1, 1), m1, m2)                         # min2_val = min_val (:181-182)
         pos = torch.arange(max_dc).view(1, 1, -1)
         minval = torch.where(pos == i1, m2, m1)                                    # [B, m, max_dc]

@@ -22,6 +22,7 @@ Sets:
   dvbs2_wrcq     (16200,7200) W-RCQ T=20, 1 codeword              (--slow, ~15 min)
   grad_toy/small d loss/d beta, d loss/d alpha of the reference under torch autograd (the loss of
                  training_framework.py:101), Neural2D types 1-4 and the per-edge NeuralMinSumDecoder
+  grad_ties      the same plus d loss/d llr on half-integer LLRs: exact ties for the second minimum (autograd splits evenly)
 """
 import argparse
 import os
@@ -769,6 +770,72 @@ def gen_grad_llr():
     return out
 
 
+def gen_grad_ties():
+    """Inputs with EXACT ties among the magnitudes a check sees (half-integer LLRs): the reference's `torch.min(temp_mags)`
+    (neural_2d_decoder.py:179, a full reduction) splits the gradient of the second minimum evenly among the tied edges,
+    `magnitudes[min_idx]` sends the minimum's to the first arg-min.  Visible in d loss/d llr (iteration 0 reads the LLRs)
+    and, through later iterations, in the table gradients.  Toy code and the 48x96 code; Neural2D type 2 and the offset form."""
+    import torch.nn.functional as F
+    import grad_oracle
+    rng = np.random.default_rng(2468)
+    out = {}
+    T = 3
+    cases = [("toy", ref_ldpc.create_test_ldpc_code(), 40)]
+    Hs = load_edge_list("small_96_48")
+    cases.append(("small", CachedCode(n=96, k=48, H=Hs, max_iterations=10), 6))
+    for tag, code, count in cases:
+        H = code.H
+        g = oracle.OracleGraph(H)
+        llrs = (np.round(rng.normal(0.9, 1.7, (count, code.n)) * 2) / 2).astype(np.float32)
+        llrs[llrs == 0] = 0.5
+        # ties the first check sweep sees: per check, edges sharing the second-smallest magnitude (arg-min edge removed)
+        ties = 0
+        for x in llrs:
+            for i in range(g.m):
+                a = np.abs(x[g.var_idx[g.check_ptr[i]:g.check_ptr[i + 1]]])
+                if len(a) > 1:
+                    rest = np.delete(a, int(np.argmin(a)))
+                    ties += int(np.sum(rest == rest.min()) > 1)
+        assert ties >= 10, ties
+        out[f"{tag}_llr"] = llrs
+        out[f"{tag}_tied_checks"] = np.int32(ties)
+        if tag == "toy":
+            out["toy_H"] = H.astype(np.uint8)
+        for kind, cls in (("n2d", ref_n2d.Neural2DMinSumDecoder), ("oms", ref_n2d.Neural2DOffsetMinSumDecoder)):
+            off = kind == "oms"
+            dec = cls(code, weight_sharing_type=2, max_iterations=T)
+            beta, alpha = set_weights(dec, rng, *((0.0, 0.6, 0.0, 0.3) if off else ()))
+            gb = {k: 0.0 for k in dec.beta_weights.keys()}
+            ga = {k: 0.0 for k in dec.alpha_weights.keys()}
+            gl, its = [], []
+            for x in llrs:
+                dec.zero_grad()
+                t = torch.from_numpy(x.copy()).requires_grad_(True)
+                _, p, i = dec(t)
+                F.binary_cross_entropy_with_logits(-p, torch.zeros_like(p)).backward()
+                gl.append(t.grad.numpy().copy()); its.append(int(i))
+                for k, w in dec.beta_weights.items():
+                    gb[k] += 0.0 if w.grad is None else float(w.grad.item())
+                for k, w in dec.alpha_weights.items():
+                    ga[k] += 0.0 if w.grad is None else float(w.grad.item())
+            gl, its = np.stack(gl), np.asarray(its, np.int32)
+            dflt = dict(beta_default=0.0, alpha_default=0.0)
+            bt, bs, at, as_ = oracle.weight_tables(g, 2, T, beta, alpha, **(dflt if off else {}))
+            gbt, _, gat, _ = oracle.weight_tables(g, 2, T, gb, ga, **dflt)
+            og = grad_oracle.table_grads(g, llrs, bt, bs, at, as_[g.var_idx] if off else as_, T, want_llr=True, offset=off)
+            check_equal(f"grad ties iters ({tag} {kind})", og[3].astype(np.int32), its)
+            for what, a, b in (("llr", og[4], gl), ("beta", og[0], gbt), ("alpha", og[1], gat)):
+                if not np.allclose(a, b, rtol=2e-4, atol=2e-6):
+                    raise SystemExit(f"GRAD ORACLE MISMATCH (ties, {tag} {kind}): d loss/d {what}: {np.abs(a - b).max()}")
+            bk, bv = pack_weights(beta); ak, av = pack_weights(alpha)
+            out.update({f"{tag}_{kind}_T": np.int32(T), f"{tag}_{kind}_iters": its, f"{tag}_{kind}_grad_llr": gl,
+                        f"{tag}_{kind}_beta_keys": bk, f"{tag}_{kind}_beta_vals": bv,
+                        f"{tag}_{kind}_alpha_keys": ak, f"{tag}_{kind}_alpha_vals": av,
+                        f"{tag}_{kind}_grad_beta_table": gbt.astype(np.float64),
+                        f"{tag}_{kind}_grad_alpha_table": gat.astype(np.float64)})
+    return out
+
+
 SETS = {
     "quantizer": gen_quantizer,
     "sums": gen_sums,
@@ -789,6 +856,7 @@ SETS = {
     "grad_small": lambda: gen_grad("small"),
     "grad_ira": lambda: gen_grad("ira"),
     "grad_llr_toy": gen_grad_llr,
+    "grad_ties": gen_grad_ties,
 }
 SLOW = {"dvbs2_wrcq": gen_dvbs2_wrcq}
 

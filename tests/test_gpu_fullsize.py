@@ -303,11 +303,14 @@ def test_bench_default_run_carries_every_baseline_config(gpu_device):
     """the default invocation (what the driver runs) reports configs 3, 4, 5 and the float64 Basic decoder as legs"""
     d = run_bench(["--steps", "3", "--warmup", "1", "--leg-steps", "2", "--sweep-reps", "4", "--no-cpu-baseline"])
     assert d["config"]["batch_per_gpu"] == 65536 and "workloads" in d
-    for w in ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64"):
+    for w in ("neural2d", "rcq", "wrcq_dvbs2", "basic_f64", "rcq_layered"):
         leg = d["workloads"][w]
         assert leg["value"] > 0 and leg["ms_per_step"] > 0 and "roofline" in leg and "workload" in leg
     assert d["workloads"]["wrcq_dvbs2"]["batch"] == 32768 and d["workloads"]["wrcq_dvbs2"]["engine"]["engine"] == "stream"
     assert d["workloads"]["basic_f64"]["dtype"] == "f64"
+    lay = d["workloads"]["rcq_layered"]                 # SURVEY 8f-3: the LDS-resident layered kernel, 4 codewords per one-wave workgroup
+    assert lay["engine"]["engine"] == "resident" and lay["engine"]["threads_per_workgroup"] == 64
+    assert lay["roofline"]["bound"] == "latency" and lay["roofline"]["dependent_steps"] == 4860 and lay["value"] > 4e6
 
 
 @pytest.mark.parametrize("engine_mode", ["auto"], indirect=True)

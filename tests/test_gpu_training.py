@@ -393,6 +393,44 @@ def test_golden_input_gradient(gpu_device, kind):
     np.testing.assert_allclose(x1.grad.numpy(), gold[f"{kind}_grad_llr"][3], rtol=1e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("tag", ["toy", "small"])
+@pytest.mark.parametrize("kind", ["n2d", "oms"])
+def test_golden_gradients_on_exact_ties(gpu_device, tag, kind):
+    """the reference under autograd on half-integer LLRs (exact ties for the second minimum of a check): its torch.min
+    splits that gradient evenly among the tied edges -- d loss/d llr and the weight gradients of the HIP backward sweeps
+    must follow (tests/golden/grad_ties.npz; round 2 sent the whole gradient to the first tied edge)"""
+    import codes
+    from ldpc_decoder import LDPCCode
+    from neural_2d_decoder import Neural2DMinSumDecoder, Neural2DOffsetMinSumDecoder
+    import oracle
+    gold = load_golden("grad_ties")
+    T = int(gold[f"{tag}_{kind}_T"])
+    if tag == "toy":
+        H = gold["toy_H"].astype(np.int64)
+        code = LDPCCode(n=H.shape[1], k=H.shape[1] - H.shape[0], H=H, max_iterations=T)
+    else:
+        code = codes.load_code("small_96_48", T)
+    dec = (Neural2DMinSumDecoder if kind == "n2d" else Neural2DOffsetMinSumDecoder)(code, 2, T)
+    beta = weights_dict(gold[f"{tag}_{kind}_beta_keys"], gold[f"{tag}_{kind}_beta_vals"])
+    alpha = weights_dict(gold[f"{tag}_{kind}_alpha_keys"], gold[f"{tag}_{kind}_alpha_vals"])
+    sd = {f"beta_weights.{k}": torch.tensor([v]) for k, v in beta.items()}
+    sd.update({f"alpha_weights.{k}": torch.tensor([v]) for k, v in alpha.items()})
+    dec.load_state_dict(sd)
+    x = torch.from_numpy(gold[f"{tag}_llr"]).to(gpu_device).requires_grad_(True)
+    _, post, iters = dec(x)
+    np.testing.assert_array_equal(iters.cpu().numpy(), gold[f"{tag}_{kind}_iters"])
+    codeword_loss_sum(post).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gold[f"{tag}_{kind}_grad_llr"], rtol=1e-4, atol=2e-6)
+    # weight gradients: the reference's per-key values flattened to [T][slots] tables by the oracle's independent flattening
+    tg = code.tanner_graph()
+    og = oracle.OracleGraph(n=tg.n, check_ptr=tg.check_ptr, var_idx=tg.var_idx)
+    gb = {k: (0.0 if p.grad is None else float(p.grad.item())) for k, p in dec.beta_weights.items()}
+    ga = {k: (0.0 if p.grad is None else float(p.grad.item())) for k, p in dec.alpha_weights.items()}
+    gbt, _, gat, _ = oracle.weight_tables(og, 2, T, gb, ga, beta_default=0.0, alpha_default=0.0)
+    np.testing.assert_allclose(gbt, gold[f"{tag}_{kind}_grad_beta_table"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(gat, gold[f"{tag}_{kind}_grad_alpha_table"], rtol=1e-4, atol=2e-6)
+
+
 def test_input_gradient_vs_oracle_on_the_1998_code(gpu_device):
     import codes
     import grad_oracle

@@ -191,3 +191,28 @@ def test_gradient_oracle_input_gradient_equals_reference_autograd(oracle_mod):
     out = grad_oracle.table_grads(g, gold["llr"], bt, bs, at, as_[g.var_idx], T, offset=True, want_llr=True)
     np.testing.assert_array_equal(out[3], gold["oms_iters"])
     np.testing.assert_allclose(out[4], gold["oms_grad_llr"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["toy", "small"])
+@pytest.mark.parametrize("kind", ["n2d", "oms"])
+def test_gradient_oracle_on_exact_ties_equals_reference_autograd(tag, kind, oracle_mod):
+    """half-integer LLRs: several edges of a check share the second-smallest magnitude; the reference's torch.min(temp_mags)
+    splits that gradient evenly (neural_2d_decoder.py:179).  d loss/d llr and both table gradients against the reference's."""
+    import codes
+    import grad_oracle
+    gold = load_golden("grad_ties")
+    assert int(gold[f"{tag}_tied_checks"]) >= 10
+    if tag == "toy":
+        g = oracle_mod.OracleGraph(gold["toy_H"].astype(np.int64))
+    else:
+        tg = codes.load_code("small_96_48", 10).tanner_graph()
+        g = oracle_mod.OracleGraph(n=tg.n, check_ptr=tg.check_ptr, var_idx=tg.var_idx)
+    T, off = int(gold[f"{tag}_{kind}_T"]), kind == "oms"
+    dflt = dict(beta_default=0.0, alpha_default=0.0) if off else {}
+    bt, bs, at, as_ = oracle_mod.weight_tables(g, 2, T, weights_dict(gold[f"{tag}_{kind}_beta_keys"], gold[f"{tag}_{kind}_beta_vals"]),
+                                               weights_dict(gold[f"{tag}_{kind}_alpha_keys"], gold[f"{tag}_{kind}_alpha_vals"]), **dflt)
+    out = grad_oracle.table_grads(g, gold[f"{tag}_llr"], bt, bs, at, as_[g.var_idx] if off else as_, T, offset=off, want_llr=True)
+    np.testing.assert_array_equal(out[3], gold[f"{tag}_{kind}_iters"])
+    np.testing.assert_allclose(out[4], gold[f"{tag}_{kind}_grad_llr"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(out[0], gold[f"{tag}_{kind}_grad_beta_table"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(out[1], gold[f"{tag}_{kind}_grad_alpha_table"], rtol=2e-4, atol=2e-6)

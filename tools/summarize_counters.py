@@ -29,3 +29,9 @@ with open(out, "w", newline="") as fh:
     for k in sorted(d):
         w.writerow([k, d[k]])
 print(open(out).read())
+# per-launch counter values bench.py prices the kernel's instruction-issue and LDS-pipe limits with (roofline.valu_issue)
+import json
+cj = os.path.join(ROOT, "profiles", "counters.json")
+db = json.load(open(cj)) if os.path.exists(cj) else {}
+db.setdefault(workload, {})[kernel] = {"source": os.path.basename(out), **{k: avg[k] for k in sorted(avg)}}
+json.dump(db, open(cj, "w"), indent=1)
