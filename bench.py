@@ -471,6 +471,19 @@ def copy_ceiling(device, torch):
     return best
 
 
+def fill_ceiling(device, torch):
+    """Measured WRITE ceiling of this box: a 1 GiB device fill (write-only, no read), best of 6, GB/s.  A 1:1 read/write
+    stream such as the CN->VN sweep cannot move more than twice this; the copy ceiling above is the same statement for a
+    library copy kernel."""
+    dst = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    best = 0.0
+    for _ in range(6):
+        ms = event_ms(lambda: dst.fill_(1.0), 1, torch)
+        best = max(best, dst.numel() * 4 / (ms * 1e-3) / 1e9)
+    del dst
+    return best
+
+
 def measure_leg(workload, device, snr_db, steps, reps, copy_gbs, with_cpu, torch):
     """one bounded leg of another BASELINE config on this GPU: decode rate + the roofline of its dominant kernel"""
     gname, T, B, dtype, desc = WORKLOADS[workload]
@@ -784,8 +797,13 @@ def main():
         reps = max(args.sweep_reps, 1)
         bm = byte_model(args.workload, g, T, B)
         copy_gbs = copy_ceiling(device, torch)
+        out["measured_ceilings"] = {"copy_GBps": copy_gbs, "fill_GBps": fill_ceiling(device, torch),
+                                    "note": "1 GiB device copy (read + write bytes) and 1 GiB device fill (write only), best of 6; "
+                                            "a sweep that writes as much as it reads is bounded by 2 x fill"}
         run = lambda: eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
-        if eng.info()["engine"] == "resident":
+        if args.workload == "rcq_layered":
+            out["roofline"] = layered_roofline(eng, g, T, B, event_ms(run, max(reps // 4, 2), torch))
+        elif eng.info()["engine"] == "resident":
             # dominant kernel = ldpc::resident_decode (the whole decode is this one launch), timed with HIP events
             ms = event_ms(run, reps, torch)
             out["roofline"] = resident_roofline(eng, args.workload, g, T, B, ms, copy_gbs)

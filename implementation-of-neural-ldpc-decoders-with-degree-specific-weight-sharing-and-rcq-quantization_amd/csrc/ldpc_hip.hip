@@ -1096,17 +1096,44 @@ int build_layered_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     while (cw > 1 && (size_t)cw * lay_row_bytes(g->n) > kLdsBytes) cw >>= 1;
     if ((size_t)cw * lay_row_bytes(g->n) > kLdsBytes) return LDPC_OK;  // one codeword's posteriors exceed LDS
     const int m_pad = (g->m + kLayPf - 1) / kLayPf * kLayPf;
+    if ((size_t)g->n * 4u + 4u > kLayOffMask) return LDPC_OK;
     const uint32_t none = (uint32_t)g->n * 4u;                        // the codeword's +inf word
-    std::vector<uint32_t> off((size_t)(m_pad + kLayPf) * lw, none);
+    std::vector<uint32_t> off((size_t)(m_pad + 2 * kLayPf) * lw, none);
     bool deg1 = false;
-    for (int i = 0; i < g->m; ++i) {
-        const int e0 = g->h_check_ptr[i], dc = g->h_check_ptr[i + 1] - e0;
+    // edges right-aligned in ascending variable order: the last lane holds the highest variable of the check
+    auto var_at = [&](int row, int t) -> int {                       // variable in lane t of plan row `row`, -1: none
+        if (row >= g->m) return -1;
+        const int e0 = g->h_check_ptr[row], dc = g->h_check_ptr[row + 1] - e0, k = t - (lw - dc);
+        return k >= 0 ? g->h_var_idx[e0 + k] : -1;
+    };
+    std::vector<char> group_late((size_t)m_pad / kLayPf, 0);
+    group_late[0] = 1;                                                // its first row follows the previous iteration's last check
+    for (int i = 0; i < m_pad; ++i) {
+        const int dc = i < g->m ? g->h_check_ptr[i + 1] - g->h_check_ptr[i] : 0;
         deg1 = deg1 || dc == 1;
+        // dependence on the previous plan row
+        const int p = (i + m_pad - 1) % m_pad;
+        int shared = 0, src_lane = -1, dst_lane = -1;
         for (int t = 0; t < lw; ++t) {
-            uint32_t o = t < dc ? (uint32_t)g->h_var_idx[e0 + t] * 4u : none;
-            off[(size_t)i * lw + t] = o | (dc == 1 ? 0x80000000u : 0u);
+            const int v = var_at(i, t);
+            if (v < 0) continue;
+            for (int u = 0; u < lw; ++u)
+                if (var_at(p, u) == v) { ++shared; src_lane = u; dst_lane = t; }
+        }
+        // one common variable whose lane in this row is the lower neighbour of its lane in the previous row: forwarded by a
+        // DPP row_shl:1 (row = 16 lanes; the pair must not straddle a DPP row).  Right-aligned ascending order makes the
+        // parity chain of staircase codes exactly that.  Anything else with a common variable: LATE (its whole group).
+        const bool fwd = shared == 1 && src_lane == dst_lane + 1 && (src_lane / 16 == dst_lane / 16);
+        if (shared > 0 && !fwd) group_late[(size_t)i / kLayPf] = 1;
+        for (int t = 0; t < lw; ++t) {
+            const int v = var_at(i, t);
+            const uint32_t o = v >= 0 ? (uint32_t)v * 4u : none;
+            off[(size_t)i * lw + t] = o | ((fwd && t == dst_lane) ? kLayFwdBit : 0u) | (dc == 1 ? kLayDeg1Bit : 0u);
         }
     }
+    for (size_t gi = 0; gi < group_late.size(); ++gi)
+        if (group_late[gi])
+            for (int t = 0; t < lw; ++t) off[gi * kLayPf * lw + t] |= kLayLateBit;
     // magnitude 0 reconstructs to 0 under every quantiser (rcq_decoder.py:79-85, :107-119): tau_0 == 0 and no later
     // threshold <= 0 -- true for the reference's C * (j / (2^(bc-1) - 1))^gamma with gamma > 0
     bool zero0 = true;
@@ -1118,8 +1145,16 @@ int build_layered_plan(ldpc_decoder *d, const ldpc_decoder_desc *desc)
     }
     int rc = upload(&d->lay_off, off.data(), off.size());
     if (rc) return rc;
-    d->lay = LayeredPlan{g->n, g->m, lw, cw, m_pad, deg1 ? 1 : 0, zero0 ? 1 : 0, d->lay_off};
-    d->lay_lds = (size_t)cw * lay_row_bytes(g->n);
+    bool sorted = true;                                               // tau_1 <= tau_2 <= ... under every quantiser
+    for (int q = 0; q < d->n_quant; ++q)
+        for (int k = 2; k < d->n_levels; ++k)
+            sorted = sorted && desc->thresholds[(size_t)q * d->n_levels + k - 1] <= desc->thresholds[(size_t)q * d->n_levels + k];
+    // A power-of-two region per codeword (address = offset | row bits, one v_and_or_b32) was measured and dropped: 4 x 8192 bytes
+    // leave room for only four workgroups per CU instead of five and put the four rows of a wave on the same LDS banks
+    // ((1998,1512): 11.2 vs 9.6 ms, profiles/r03_layered_variants.txt).  The kernel keeps the template flag for A/B builds.
+    const int row_shift = 0;
+    d->lay = LayeredPlan{g->n, g->m, lw, cw, m_pad, deg1 ? 1 : 0, zero0 ? 1 : 0, sorted ? 1 : 0, row_shift, d->lay_off};
+    d->lay_lds = row_shift ? ((size_t)cw << row_shift) : (size_t)cw * lay_row_bytes(g->n);
     d->lay_ok = true;
     return LDPC_OK;
 }
@@ -1131,9 +1166,9 @@ int decode_layered_lds(const ldpc_decoder *d, const void *llr, int64_t batch, in
     hipStream_t s = (hipStream_t)stream;
     const LayeredPlan &pl = d->lay;
     const unsigned blocks = (unsigned)((batch + pl.cw - 1) / pl.cw);
-#define LDPC_LAY_K(LW_, NL_, ES_, D1_, Z0_)                                                                          \
+#define LDPC_LAY_K(LW_, NL_, ES_, D1_, Z0_, SO_)                                                                     \
     do {                                                                                                             \
-        auto kfn = layered_lds<LW_, NL_, ES_, D1_, Z0_>;                                                             \
+        auto kfn = pl.row_shift ? layered_lds<LW_, NL_, ES_, D1_, Z0_, SO_, true> : layered_lds<LW_, NL_, ES_, D1_, Z0_, SO_, false>; \
         if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                   \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kWave), d->lay_lds, s, pl, (const float *)llr, (long long)batch, \
                            (const float *)d->thresholds, d->n_levels, (const int *)d->q_of_iter_dev, d->T,           \
@@ -1143,9 +1178,9 @@ int decode_layered_lds(const ldpc_decoder *d, const void *llr, int64_t batch, in
     // everything else the general one (run-time level count, degree-1 flag, the reference's "w < 0" sign test)
 #define LDPC_LAY_NL(LW_)                                                                                             \
     do {                                                                                                             \
-        const bool lean = d->n_levels == 4 && !pl.has_deg1 && pl.zero0;                                              \
-        if (lean) { if (early_stop) LDPC_LAY_K(LW_, 4, true, false, true); else LDPC_LAY_K(LW_, 4, false, false, true); } \
-        else { if (early_stop) LDPC_LAY_K(LW_, 0, true, true, false); else LDPC_LAY_K(LW_, 0, false, true, false); } \
+        const bool lean = d->n_levels == 4 && !pl.has_deg1 && pl.zero0 && pl.sorted;                                 \
+        if (lean) { if (early_stop) LDPC_LAY_K(LW_, 4, true, false, true, true); else LDPC_LAY_K(LW_, 4, false, false, true, true); } \
+        else { if (early_stop) LDPC_LAY_K(LW_, 0, true, true, false, false); else LDPC_LAY_K(LW_, 0, false, true, false, false); } \
     } while (0)
     switch (pl.lw) {
     case 1: LDPC_LAY_NL(1); break;

@@ -18,6 +18,24 @@
 // is the only global-memory access of the loop.  LLRs come straight from the caller's rows and the outputs go straight
 // back (no tile transposes, no workspace).  Several single-wave workgroups share a CU (five on the (1998,1512) code).
 //
+// What a step costs: ~36 instructions, half of them with a DPP operand (the butterfly), issued by ONE wave per SIMD -- a wave
+// issues a dependent VALU instruction every ~9 cycles, a DPP one every ~16 with its hazard slot
+// (tools/probes/valu_latency_probe.hip) -- so the quantise/select tail is scheduled by hand (ten instructions, no hazard
+// padding) and the step is bounded by VALU time, not by the LDS round trip.
+//
+// A/B form (-DLDPC_LAY_EARLY=1, measured slower at full occupancy, see the macro below): the LDS round trip taken OFF the
+// chain where the graph allows it -- the posteriors of check i+1 are read one step
+// EARLY (before check i has written), which is exact for every lane whose variable check i does not touch.  The host knows
+// which lanes those are; per plan row it records how the row depends on the previous one:
+//   NONE  no common variable                         -> the early values are the values
+//   FWD   exactly one common variable, sitting in the LAST lane of the previous row and the last-but-one of this row (edges
+//         are laid out right-aligned in ascending variable order, so this is the dual-diagonal parity chain of IRA /
+//         DVB-S2-like codes: check i = {..., p_i-1, p_i})  -> that lane takes the value the previous step just wrote from
+//         its neighbour lane (one DPP move), all others keep the early value
+//   LATE  anything else                              -> the row is read again after the previous write (the plain in-order form;
+//         decided per GROUP of four rows so that the fast groups carry no test and no branch per step)
+// (the plan always carries these flags; the default in-order form ignores them).
+//
 // Arithmetic is that of layered_rcq (same helpers): results are identical to the streaming kernel's.
 #pragma once
 
@@ -30,15 +48,33 @@ struct LayeredPlan {
     int m_pad;                     // plan rows walked: m rounded up to a multiple of kLayPf with no-op rows (every lane at +inf)
     int has_deg1;                  // some check has exactly one edge (its entries carry bit 31)
     int zero0;                     // every quantiser reconstructs magnitude 0 as 0 (tau_0 == 0, the other thresholds > 0)
-    const uint32_t *off;           // [m_pad + kLayPf][lw]  LDS byte offset (4 * variable) of edge t of check i; lanes without an
+    int sorted;                    // tau_1 <= tau_2 <= ... under every quantiser
+    int row_shift;                 // > 0: a codeword's LDS region is 2^row_shift bytes (its address is then offset | row bits: one
+                                   // v_and_or_b32); 0: (n + 1) * 4 bytes, packed
+    const uint32_t *off;           // [m_pad + 2 * kLayPf][lw]  bits 0..28: LDS byte offset (4 * variable) of the edge in lane t of check
+                                   //          i (edges right-aligned, ascending variable order); lanes without an
                                    //          edge point at word n of the codeword's vector, which holds +inf for ever (it
                                    //          is neutral for min and parity, and inf + message = inf is written back);
-                                   //          bit 31 set on the entries of a degree-1 check ("min2 = min", :312-313);
-                                   //          no-op rows up to m_pad (inf in, inf out), then kLayPf more that only the prefetch
-                                   //          past the last check reads
+                                   //          bit 31 (kLayFwdBit): THIS lane takes its value from its upper neighbour lane of the
+                                   //          previous step (FWD rows: the one receiving lane); bit 30 (kLayLateBit), on every lane
+                                   //          of the FIRST row of a group of kLayPf rows: some row of the group must be read after
+                                   //          the previous row's write (the whole group then runs in order; group 0 always);
+                                   //          bit 29 (kLayDeg1Bit) on the entries of a degree-1 check ("min2 = min", :312-313);
+                                   //          no-op rows up to m_pad (inf in, inf out), then 2 * kLayPf more that only the
+                                   //          prefetch past the last check reads
 };
 
 constexpr int kLayPf = 4;          // plan entries in flight ahead of the check being processed (= the unroll of the walk)
+#ifndef LDPC_LAY_EARLY
+#define LDPC_LAY_EARLY 0           // 1: early reads + DPP forwarding of the parity chain (header); 0: every row is read after the previous
+                                   // write.  Same-box A/B on the (1998,1512) code, 65536 codewords, T = 10
+                                   // (profiles/r03_layered_variants.txt): in order 8.87-8.90 ms, early form 9.23-9.25 ms (both 0.66-0.68 ms
+                                   // at 4096 codewords, where a wave has its SIMD to itself): a step is bounded by the VALU time of its
+                                   // ~19 DPP operations, not by the LDS round trip, and the in-order form's LDS waits are what the
+                                   // fifth wave of a CU fills.
+#endif
+constexpr uint32_t kLayOffMask = 0x1fffffffu;
+constexpr uint32_t kLayFwdBit = 0x80000000u, kLayLateBit = 0x40000000u, kLayDeg1Bit = 0x20000000u;
 
 // LDS bytes of one codeword: n posteriors + the +inf word
 __host__ __device__ inline size_t lay_row_bytes(int n) { return ((size_t)n + 1) * 4; }
@@ -97,7 +133,11 @@ __device__ __forceinline__ void lay_lds_st(unsigned byte_off, float v)
 // Z0: magnitude 0 reconstructs to 0 under every quantiser -- the message sign is then the parity of the other signs without
 //     the reference's "w < 0" test (it differs only in the sign of an exact zero message, which no later operation observes
 //     as a value: x + (+-0) == x, |.|, the compares; same argument as ldpc_resident.hip's per-check quantisation)
-template <int LW, int NL, bool ES, bool D1, bool Z0>
+// SORTED (NL = 4): tau_1 <= tau_2 <= tau_3 -- the level is then found by a two-deep select tree, and BOTH candidate outputs
+//     (reconstruction of min1 and of min2) are formed side by side right after the butterfly; the lane only picks.  On one
+//     wave a dependent VALU instruction issues every ~9 cycles and a compare -> select pair costs ~21
+//     (tools/probes/valu_latency_probe.hip), so the depth of this tail, not its instruction count, is what a step costs.
+template <int LW, int NL, bool ES, bool D1, bool Z0, bool SORTED = false, bool P2 = false>
 __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float *__restrict__ llr, long long batch,
                                                      const float *__restrict__ thresholds, int n_levels,
                                                      const int *__restrict__ q_of_iter, int T,
@@ -115,8 +155,10 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
     // values written to the same addresses -- they must take every decision (frozen, latch) exactly as the group they shadow
     const int row_eff = min(row, cw - 1);
     const bool row_live = b0 + row_eff < batch;                     // this lane's codeword exists (padding rows of the last wave do not)
-    const unsigned row_words = (unsigned)n + 1u;
+    const unsigned row_words = P2 ? (1u << pl.row_shift) / 4u : (unsigned)n + 1u;
     const unsigned row_base = (unsigned)row_eff * row_words * 4u;
+    // LDS address of a plan entry: P2 -> the row bits are disjoint from the offset bits, mask and combine are one instruction
+    auto lds_addr = [&](uint32_t o) { return P2 ? ((o & kLayOffMask) | row_base) : (row_base + (o & kLayOffMask)); };
 
     // LLRs: the caller's rows, coalesced (all 64 lanes over one row at a time); "posteriors = llr.clone()" (:288)
     for (int r = 0; r < cw; ++r) {
@@ -140,7 +182,7 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
 #pragma unroll 4
         for (int i = 0; i < m; ++i) {
             const uint32_t o = plan[(size_t)i * LW];
-            unsigned s = lay_lds_ld(row_base + (o & 0x7fffffffu)) < 0.0f ? 1u : 0u;
+            unsigned s = lay_lds_ld(lds_addr(o)) < 0.0f ? 1u : 0u;
             lay_step_xor<1, LW>(s); lay_step_xor<2, LW>(s); lay_step_xor<4, LW>(s);
             lay_step_xor<8, LW>(s); lay_step_xor<16, LW>(s); lay_step_xor<32, LW>(s);
             unsat |= s;
@@ -158,15 +200,66 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
             else th[q] = (q < n_levels) ? thr[q] : __builtin_nanf("");
             asm volatile("" : "+v"(th[q]));                         // in VGPRs for the whole walk (a select takes one scalar operand: its mask)
         }
-        // one check: o = this lane's plan entry
-        auto step = [&](uint32_t o) {
-            const unsigned addr = row_base + (D1 ? (o & 0x7fffffffu) : o);
-            const float x = lay_lds_ld(addr);
+        // one check: o = this lane's plan entry, on = its entry of the NEXT row (whose posteriors are requested here, one step
+        // early); xe = this row's early value, upd_prev = what this lane wrote in the previous step
+        float xe = 0.0f, upd_prev = 0.0f;
+        auto step = [&](uint32_t o, uint32_t on, auto late_tag) {
+            constexpr bool kLate = decltype(late_tag)::value;
+            const unsigned addr = lds_addr(o);
+            // the NEXT row's posteriors first -- before this row's write, a whole step before they are needed (the scheduling
+            // barrier keeps the compiler from sinking the request towards its use)
+#if LDPC_LAY_EARLY
+            const float x_early = xe;
+            xe = lay_lds_ld(lds_addr(on));
+            __builtin_amdgcn_sched_barrier(0);
+            float x = x_early;
+#else
+            (void)on;
+            float x = lay_lds_ld(addr);                             // in order: after the previous row's write
+#endif
+            if constexpr (!LDPC_LAY_EARLY) {
+            } else if constexpr (kLate) {
+                // a group with a LATE row (or the first group of an iteration): every row of it is read after the previous
+                // write.  The wait sits INSIDE the asm, so the compiler's own counters -- and with them the fast groups --
+                // never drain the LDS queue.
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(addr) : "memory");
+            } else if (LW >= 2) {
+                // FWD: the flagged lane <- its upper neighbour's value of the previous step (row_shl:1)
+                const float f = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(upd_prev), 0x101, 0xf, 0xf, true));
+                x = ((int)o < 0) ? f : x;
+            }
             const unsigned xb = __float_as_uint(x), a = xb & 0x7fffffffu;
             unsigned m1 = a, m2 = 0x7f800000u, par = xb;
             lay_step<1, LW>(m1, m2, par); lay_step<2, LW>(m1, m2, par); lay_step<4, LW>(m1, m2, par);
             lay_step<8, LW>(m1, m2, par); lay_step<16, LW>(m1, m2, par); lay_step<32, LW>(m1, m2, par);
-            if (D1 && (o & 0x80000000u)) m2 = m1;                   // degree-1 check: "min2_val = min_val" (:312-313)
+            if (D1 && (o & kLayDeg1Bit)) m2 = m1;                   // degree-1 check: "min2_val = min_val" (:312-313)
+            float msg;
+            if constexpr (NL == 4 && SORTED && Z0) {
+                // raw = min over the OTHER edges (arg-min edge takes min2; ties make min2 == min1); rec = tau[last q with raw >=
+                // tau_q]; sorted thresholds: c3 => c2 => c1, so rec = c2 ? (c3 ? tau3 : tau2) : (c1 ? tau1 : tau0).  Scheduled by
+                // hand -- ten instructions, every compare two or more instructions ahead of the select that reads its mask; the
+                // compiler routes every compare/select pair through vcc with an s_nop each.  (One wave issues an instruction
+                // every 6-9 cycles whatever it is -- tools/probes/valu_latency_probe.hip -- so a step costs its instruction
+                // COUNT: forming both candidates side by side was measured slower than this.)
+                float rec, raw, lo, hi;
+                unsigned long long ca, cb;
+                unsigned sgn;                                        // par ^ x: formed inside the block, in a hazard slot
+                asm("v_cmp_eq_u32_e32 vcc, %[a], %[m1]\n\t"
+                    "v_xor_b32_e32 %[sgn], %[par], %[xb]\n\t"
+                    "s_nop 0\n\t"
+                    "v_cndmask_b32_e32 %[raw], %[m1], %[m2], vcc\n\t"
+                    "v_cmp_le_f32_e64 %[ca], %[t1], %[raw]\n\t"
+                    "v_cmp_le_f32_e64 %[cb], %[t3], %[raw]\n\t"
+                    "v_cmp_le_f32_e32 vcc, %[t2], %[raw]\n\t"
+                    "v_cndmask_b32_e64 %[lo], %[t0], %[t1], %[ca]\n\t"
+                    "v_cndmask_b32_e64 %[hi], %[t2], %[t3], %[cb]\n\t"
+                    "v_cndmask_b32_e32 %[rec], %[lo], %[hi], vcc"
+                    : [rec] "=v"(rec), [raw] "=&v"(raw), [lo] "=&v"(lo), [hi] "=&v"(hi), [sgn] "=&v"(sgn), [ca] "=&s"(ca), [cb] "=&s"(cb)
+                    : [t0] "v"(th[0]), [t1] "v"(th[1]), [t2] "v"(th[2]), [t3] "v"(th[3]), [m1] "v"(m1), [m2] "v"(m2), [a] "v"(a),
+                      [par] "v"(par), [xb] "v"(xb)
+                    : "vcc");
+                msg = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(rec), sgn, 0x80000000u, 0x78));   // a ^ (b & c)
+            } else {
             const float raw = __uint_as_float((a == m1) ? m2 : m1);  // arg-min edge; ties make min2 == min1
             float rec;
             if constexpr (NL > 0) {
@@ -183,30 +276,42 @@ __global__ __launch_bounds__(kWave) void layered_lds(LayeredPlan pl, const float
             }
             // message = (1 - 2*sign_bit) * tau[level] (:107-119), sign_bit = (sign * raw < 0): the parity of the OTHER edges'
             // sign bits (bit 31 of par ^ x), counted only for a non-zero magnitude
-            float msg;
             if constexpr (Z0) {
                 msg = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(rec), par ^ xb, 0x80000000u, 0x78));   // a ^ (b & c)
             } else {
                 const unsigned neg = (raw > 0.0f) ? ((par ^ xb) & 0x80000000u) : 0u;
                 msg = __uint_as_float(__float_as_uint(rec) ^ neg);
             }
+            }
             float upd = x + msg;                                    // "posteriors[j] += c2v_messages[i, j]" (:337-338)
             if (ES) upd = frozen ? x : upd;                         // a stopped codeword keeps its posteriors
             lay_lds_st(addr, upd);
+            upd_prev = upd;
         };
-        // plan entries of the NEXT group of kLayPf checks are requested before the current group is walked: they have a
-        // whole group (~1000 cycles) to arrive.  m is a multiple of kLayPf and kLayPf more rows follow: no bounds tests.
-        uint32_t cur[kLayPf], nxt[kLayPf];
+        // Plan entries are requested a group ahead: rows 1.. of the NEXT group, and row 0 of the group after it (row 0 of the
+        // next group is needed already by the LAST step of this one, for its early read -- it was requested a group ago).
+        // m is a multiple of kLayPf and 2 * kLayPf more rows follow: no bounds tests.
+        uint32_t cur[kLayPf], nxt[kLayPf], nn0;
 #pragma unroll
         for (int k = 0; k < kLayPf; ++k) cur[k] = plan[(size_t)k * LW];
+        nxt[0] = plan[(size_t)kLayPf * LW];
         for (int i0 = 0; i0 < m; i0 += kLayPf) {
             const uint32_t *nx = plan + (size_t)(i0 + kLayPf) * LW;
 #pragma unroll
-            for (int k = 0; k < kLayPf; ++k) nxt[k] = nx[(size_t)k * LW];
+            for (int k = 1; k < kLayPf; ++k) nxt[k] = nx[(size_t)k * LW];
+            nn0 = nx[(size_t)kLayPf * LW];
+            // one wave-uniform test per GROUP: the host flags the first row of a group that holds a LATE row (and group 0:
+            // its first row follows the previous iteration's last check); such a group runs the in-order form
+            if (LDPC_LAY_EARLY && (__builtin_amdgcn_readfirstlane(cur[0]) & kLayLateBit)) {
 #pragma unroll
-            for (int k = 0; k < kLayPf; ++k) step(cur[k]);
+                for (int k = 0; k < kLayPf; ++k) step(cur[k], k + 1 < kLayPf ? cur[k + 1] : nxt[0], std::true_type{});
+            } else {
+#pragma unroll
+                for (int k = 0; k < kLayPf; ++k) step(cur[k], k + 1 < kLayPf ? cur[k + 1] : nxt[0], std::false_type{});
+            }
 #pragma unroll
             for (int k = 0; k < kLayPf; ++k) cur[k] = nxt[k];
+            nxt[0] = nn0;
         }
         if (ES) {
             const unsigned unsat = syndrome();

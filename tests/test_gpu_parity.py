@@ -799,6 +799,43 @@ def test_host_batches_take_the_staged_path_with_identical_results(B, gpu_device)
         torch.library.opcheck(torch.ops.ldpc.decode_host, (x, h, True, True))
 
 
+def test_workspace_cache_is_bounded_and_host_staging_moves_only_the_batch(gpu_device, oracle_mod):
+    """(1) the per-stream workspace cache of an engine is a small LRU -- a caller cycling through short-lived
+    torch streams does not pile up one multi-GB buffer per stream; (2) decode_host lays its device block out for the ACTUAL
+    batch (a one-codeword call copies ~2n words back, not the 64-row block) and still equals the device path; its staging
+    lock is not the workspace lock."""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    code = codes.load_code("small_96_48", 10)
+    dec = BasicMinSumDecoder(code, 0.7)
+    eng = dec._engine(torch.float32, gpu_device)
+    eng.set_mode("stream")                               # the streaming engine is the one with a real workspace
+    rng = np.random.default_rng(3)
+    llr = awgn(rng, 70, code.n, 3.0)
+    x = torch.from_numpy(llr).to(gpu_device)
+    want = eng.decode(x)
+    keep = []
+    for _ in range(3 * eng._WS_MAX):
+        st = torch.cuda.Stream(device=gpu_device)
+        keep.append(st)
+        st.wait_stream(torch.cuda.current_stream(gpu_device))
+        with torch.cuda.stream(st):
+            got = eng.decode(x)
+        st.synchronize()
+        assert torch.equal(got.bits, want.bits) and torch.equal(got.iterations, want.iterations)
+        assert len(eng._ws) <= eng._WS_MAX
+    assert len(eng._ws) == eng._WS_MAX
+    eng.set_mode("auto")
+    assert eng._host_lock is not eng._ws_lock
+    for B in (1, 5, 64):
+        bits, post, iters, succ = eng.decode_host(torch.from_numpy(llr[:B]), want_posterior=True)
+        dev = eng.decode(x[:B])
+        assert torch.equal(bits, dev.bits.cpu()) and torch.equal(iters, dev.iterations.cpu()) and torch.equal(succ, dev.success.cpu())
+        assert torch.equal(post, dev.posterior.cpu())
+        bits2, post2, iters2, _ = eng.decode_host(torch.from_numpy(llr[:B]), want_posterior=False)
+        assert post2 is None and torch.equal(bits2, bits) and torch.equal(iters2, iters)
+
+
 def sparse_odd_code():
     """14x40 sparse code that QUALIFIES for the LDS-resident engine (dc <= 32, dv <= 8) and still has a
     degree-1 check, an empty check, an isolated variable and a degree-1 variable"""

@@ -7,6 +7,7 @@ symbol include/ldpc_hip.h declares) and the no-CPU-fallback rule.
 """
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -418,3 +419,30 @@ def test_bench_bare_launch_reports_a_failing_rank_at_once():
     assert out.returncode != 0 and out.stdout.strip() == ""
     assert "rank 0 stderr" in out.stderr and "rank 1 stderr" in out.stderr and "no CPU fallback" in out.stderr
     assert time.time() - t0 < 120
+
+
+def test_bench_issue_limits_and_layered_model_are_consistent():
+    """bench.py's counter-based limits of the resident kernel (VALU issue, LDS pipe) and the step-time model of the layered
+    kernel: pure arithmetic on files under profiles/ -- checked here so that a malformed counters.json cannot break the line"""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    cj = os.path.join(ROOT, "profiles", "counters.json")
+    ent = json.load(open(cj))["basic"]["resident_decode"]
+    lim = bench.issue_limits("basic", "resident_decode", 65536, 2.8)
+    assert lim["valu_issue"]["ms"] == pytest.approx(ent["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e9 * 1e3)
+    assert lim["lds_pipe"]["ms"] == pytest.approx(ent["SQ_LDS_IDX_ACTIVE"] / 256 / 2.4e9 * 1e3)
+    assert lim["binding"] in ("valu_issue", "lds_pipe") and 0 < lim[lim["binding"]]["frac"] <= 1.0
+    assert bench.issue_limits("basic", "resident_decode", 4096, 0.2) is None          # counters exist for the default batch only
+    assert bench.issue_limits("nope", "resident_decode", 65536, 1.0) is None
+
+    class Eng:
+        def info(self):
+            return {"engine": "resident", "codewords_per_workgroup": 4, "lds_bytes": 31984, "threads_per_workgroup": 64}
+
+    class G:
+        m, E = 486, 6587
+    r = bench.layered_roofline(Eng(), G(), 10, 65536, 9.6)
+    assert r["dependent_steps"] == 4860 and r["waves_per_cu"] == 5 and r["rounds"] == pytest.approx(65536 / 4 / (5 * 256))
+    assert r["achieved"] == pytest.approx(9.6e6 / r["rounds"] / 4860) and r["bound"] == "latency"

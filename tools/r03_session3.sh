@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 3, GPU session 2: full -m gpu suite, config 5 with the fused last pass, stream-mode (1998,1512) kernel stats, layered timing
+# round 3, GPU session 3: full -m gpu suite, config 5 with the fused last pass, stream-mode (1998,1512) kernel stats, layered timing
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03s2; rm -rf $O; mkdir -p $O
+O=gpurun_out/r03s3; rm -rf $O; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/summary.txt
 tail -12 $O/pytest.log
 timeout -k 10 200 python bench.py --workload wrcq_dvbs2 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_wrcq.json 2> $O/bench_wrcq.err; echo "bench wrcq rc=$?" | tee -a $O/summary.txt

@@ -76,7 +76,8 @@ def main():
                     best = v
             return best
 
-        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather", "cn_sweep_q4", "vn_sweep_q4"):
+        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather", "cn_sweep_q4", "vn_sweep_q4", "vn_last_rows",
+                    "transpose_in_q4", "transpose_in_v", "layered_lds"):
             v = pick(key)
             if v is not None:
                 entry[key] = {"bytes_per_launch": v, "source": src}

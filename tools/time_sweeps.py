@@ -33,7 +33,7 @@ def main():
         eng, dec, code = bench.build_decoder(a.workload, dev)
     if a.mode:
         eng.set_mode(a.mode)
-    llr = bench.make_llr(B, code.n, 2.0, 1234, dev)
+    llr = bench.make_llr(B, code.n, 2.0, 1234, dev, torch.float64 if a.workload == "basic_f64" else torch.float32)
     for _ in range(2):
         eng.decode(llr, early_stop=False, want_posterior=False, want_packed=a.packed)
     torch.cuda.synchronize()
