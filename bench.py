@@ -410,10 +410,13 @@ def layered_roofline(eng, g, T, B, ms):
     steps = g.m * T
     step_ns = ms * 1e6 / max(rounds, 1.0) / max(steps, 1)
     lds_bytes = 2.0 * 4 * g.E * T * B                                # one 4-byte read and write per edge and iteration
+    lim = issue_limits("rcq_layered", "layered_lds", B, ms)          # VALU issue / LDS pipe shares from the SQ counters on file
+    tr, src = traffic_of(load_traffic("rcq_layered"), "layered_lds", "rcq_layered", B)
     return {"bound": "latency", "kernel": "ldpc::layered_lds (layered RCQ walk, posteriors resident in LDS, lanes over the edges of a check)",
             "ms_per_launch": ms, "codewords_per_wave": cw, "waves_per_cu": per_cu, "rounds": rounds, "dependent_steps": steps,
             "achieved": step_ns, "unit": "ns per dependent check step", "cycles_per_step_at_2.4GHz": step_ns * 2.4,
-            "lds_traffic_GBps": lds_bytes / (ms * 1e-3) / 1e9, "traffic": None,
+            "peak": None, "frac": lim["valu_issue"]["frac"] if lim else None, "frac_kind": "VALU issue time / launch time",
+            "issue_limits": lim, "lds_traffic_GBps": lds_bytes / (ms * 1e-3) / 1e9, "traffic": tr, "traffic_source": src,
             "note": "latency-bound by construction: codewords in flight per CU = LDS capacity / 4n bytes; no HBM or LDS "
                     "bandwidth limit is near (HBM sees the LLRs in and the decisions out only)"}
 
@@ -472,9 +475,8 @@ def copy_ceiling(device, torch):
 
 
 def fill_ceiling(device, torch):
-    """Measured WRITE ceiling of this box: a 1 GiB device fill (write-only, no read), best of 6, GB/s.  A 1:1 read/write
-    stream such as the CN->VN sweep cannot move more than twice this; the copy ceiling above is the same statement for a
-    library copy kernel."""
+    """Measured WRITE rate of this box: a 1 GiB device fill (write-only, no read), best of 6, GB/s -- reported beside the
+    copy rate (read + write bytes of a library copy) so that a sweep's mixed read/write rate can be placed between them."""
     dst = torch.empty(1 << 28, dtype=torch.float32, device=device)
     best = 0.0
     for _ in range(6):
@@ -590,7 +592,12 @@ class ShardedRun:
         for _ in range(reps + 1):                                   # first repetition: communicator warm-up, dropped
             self.fence()
             t0 = time.perf_counter()
-            out = all_gather_hard_decisions(src, total)
+            if ctx["backend"] == "nccl":                           # the collective itself, also with one rank (RCCL's local copy)
+                import torch.distributed as dist
+                out = self.torch.empty((total, self.nbytes), dtype=self.torch.uint8, device=ctx["device"])
+                dist.all_gather_into_tensor(out, src)
+            else:
+                out = all_gather_hard_decisions(src, total)
             self.torch.cuda.synchronize(ctx["device"])
             times.append(1e3 * max_over_ranks(time.perf_counter() - t0, ctx))
         del out
@@ -675,7 +682,8 @@ def sharded_leg(workload, B, strong, ctx, args):
     per = B // world if strong else B
     run = ShardedRun(workload, per, ctx, early=False, overlap=not args.no_overlap, snr_db=args.snr_db)
     steps = max(args.leg_steps, 1)
-    elapsed = run.timed(steps, 1)
+    elapsed = run.timed(steps, 2)          # two warm-up steps: outputs alternate between two sets of buffers (the previous step's
+                                           # are still referenced while the next decode allocates), both must exist before timing
     ver = run.verify()
     ga = run.gather_alone()
     info = run.eng.info()
@@ -798,8 +806,7 @@ def main():
         bm = byte_model(args.workload, g, T, B)
         copy_gbs = copy_ceiling(device, torch)
         out["measured_ceilings"] = {"copy_GBps": copy_gbs, "fill_GBps": fill_ceiling(device, torch),
-                                    "note": "1 GiB device copy (read + write bytes) and 1 GiB device fill (write only), best of 6; "
-                                            "a sweep that writes as much as it reads is bounded by 2 x fill"}
+                                    "note": "1 GiB device copy (read + write bytes) and 1 GiB device fill (write only), best of 6"}
         run = lambda: eng.decode(llr, early_stop=early, want_bits=True, want_posterior=want_post)
         if args.workload == "rcq_layered":
             out["roofline"] = layered_roofline(eng, g, T, B, event_ms(run, max(reps // 4, 2), torch))

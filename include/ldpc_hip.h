@@ -61,6 +61,9 @@ enum {
 /* message schedule.  LAYERED_REF is RCQMinSumDecoder(layered=True) exactly as the reference runs it
  * (rcq_decoder.py:281-350): checks processed in order on running posteriors whose "previous
  * message" is never subtracted (the reference re-creates its message matrix per check); RCQ fp32 only.
+ * Two kernels with identical results: LDS-resident (posteriors of a few codewords per one-wave workgroup in LDS, the lanes
+ * on the edges of the current check; LDPC_MODE_AUTO / RESIDENT when a posterior vector fits LDS and no check has more than
+ * 64 edges) and streaming (posteriors in HBM, a lane per codeword; LDPC_MODE_STREAM and every other case).
  * LAYERED is the schedule that code sets out to implement (and the RCQ paper defines): the check's previous
  * message IS subtracted before its update and the new one added -- an extension with no reference execution
  * to compare against (parity unpinned; checked against an independent CPU restatement only). */
@@ -117,8 +120,11 @@ int ldpc_decoder_create(ldpc_decoder **out, const ldpc_graph *g, const ldpc_deco
  *                          messages from the 1-byte check->variable codes and the LLRs (no V2C array);
  *              SWEEPS forces the plain two-sweep form (fp32 V2C rows); GATHER / PAIR force that form (error when the
  *              decoder does not qualify).
+ *              On fp32 256-codeword tiles the last variable pass writes the caller's posterior / decision rows itself, and the
+ *              PAIR form's entrance pass also codes the LLRs for iteration 0 (no separate layout passes at either end).
  *   RESIDENT : one fused kernel, messages in LDS for all T iterations; fp32 codes with
- *              dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code)
+ *              dv <= 8 whose state fits 160 KiB of LDS (e.g. the (1998,1512) code); for the layered schedule: the
+ *              LDS-resident layered kernel (see LDPC_SCHED_LAYERED_REF)
  * AUTO (default) takes RESIDENT when the code qualifies, else STREAM. */
 enum { LDPC_MODE_AUTO = 0, LDPC_MODE_STREAM = 1, LDPC_MODE_RESIDENT = 2, LDPC_MODE_SWEEPS = 3, LDPC_MODE_GATHER = 4,
        LDPC_MODE_PAIR = 5 };
