@@ -58,16 +58,17 @@ def source_hash(defines=()) -> str:
     return h.hexdigest()
 
 
-def _hash_path(target: str) -> str:
-    return target + ".srchash"
-
-
 def built_hash(target: Optional[str] = None) -> Optional[str]:
-    """the source hash recorded beside a built library (None: no record)"""
+    """the source hash EMBEDDED in a built library (ldpc_source_hash(); None: not a library of this project, or a build
+    that predates the symbol).  Read through a private dlopen handle -- loading a stale library to ask what it is is harmless."""
+    target = target or os.path.join(_HERE, LIB_NAME)
     try:
-        with open(_hash_path(target or os.path.join(_HERE, LIB_NAME))) as f:
-            return f.read().strip() or None
-    except OSError:
+        lib = C.CDLL(target)
+        fn = lib.ldpc_source_hash
+        fn.restype = C.c_char_p
+        fn.argtypes = []
+        return fn().decode() or None
+    except (OSError, AttributeError):
         return None
 
 
@@ -78,7 +79,7 @@ def is_stale(target: Optional[str] = None, defines=()) -> bool:
 
 def build_native(force: bool = False, verbose: bool = False, defines=(), out: Optional[str] = None) -> str:
     """hipcc cross-compile of csrc/ldpc_hip.hip for gfx950 into the package dir; skipped when the library on disk was
-    built from exactly these sources with exactly this recipe (content hash stored in <lib>.srchash, not file times).
+    built from exactly these sources with exactly this recipe (content hash embedded in the library, not file times).
     `defines`/`out` build tuning variants (tools/sweep_variants.py)."""
     srcs = _source_files()
     target = out or os.path.join(_HERE, LIB_NAME)
@@ -87,7 +88,7 @@ def build_native(force: bool = False, verbose: bool = False, defines=(), out: Op
         return target
     hipcc = os.environ.get("HIPCC") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc")
     tmp = target + ".tmp%d" % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", tmp, srcs[0]]
+    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + [f"-DLDPC_SRC_HASH={want}", "-o", tmp, srcs[0]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
@@ -99,8 +100,6 @@ def build_native(force: bool = False, verbose: bool = False, defines=(), out: Op
             pass
         raise NativeEngineError("hipcc failed:\n" + res.stderr[-4000:])
     os.replace(tmp, target)                      # never a half-written library under the real name
-    with open(_hash_path(target), "w") as f:
-        f.write(want + "\n")
     return target
 
 
@@ -118,7 +117,7 @@ class DecoderDesc(C.Structure):
 PRODUCT_EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
                    "ldpc_decoder_set_mode", "ldpc_decoder_info",
                    "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
-                   "ldpc_decode", "ldpc_last_error", "ldpc_abi_version",
+                   "ldpc_decode", "ldpc_last_error", "ldpc_abi_version", "ldpc_source_hash",
                    "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
 # ... and the measurement / test hooks of include/ldpc_hip_debug.h (bench.py's per-kernel timing, the tests' state dumps)
 DEBUG_EXPORTS = ("ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_debug_resident_c2v")
@@ -187,6 +186,8 @@ def load():
         lib.ldpc_last_error.argtypes = []
         lib.ldpc_abi_version.restype = C.c_int
         lib.ldpc_abi_version.argtypes = []
+        lib.ldpc_source_hash.restype = C.c_char_p
+        lib.ldpc_source_hash.argtypes = []
         if lib.ldpc_abi_version() != 1:
             raise NativeEngineError("libldpc_hip.so ABI version mismatch")
         _lib = lib

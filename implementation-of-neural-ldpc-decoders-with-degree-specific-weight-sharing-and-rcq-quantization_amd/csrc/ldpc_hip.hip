@@ -1204,6 +1204,12 @@ extern "C" {
 
 const char *ldpc_last_error(void) { return g_err; }
 int ldpc_abi_version(void) { return LDPC_HIP_ABI_VERSION; }
+#ifndef LDPC_SRC_HASH
+#define LDPC_SRC_HASH unknown
+#endif
+#define LDPC_STR2(x) #x
+#define LDPC_STR(x) LDPC_STR2(x)
+const char *ldpc_source_hash(void) { return LDPC_STR(LDPC_SRC_HASH); }
 
 // Host-side containers may throw; no exception crosses the C boundary.
 #define LDPC_NOTHROW(call)                                                                     \

@@ -186,6 +186,10 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
 
 const char *ldpc_last_error(void);
 int ldpc_abi_version(void);
+/* sha256 (hex) over the sources and the compile recipe this library was built from, embedded at build time
+ * (-DLDPC_SRC_HASH=...; "unknown" for a hand build).  The Python loader compares it with the sources on disk and
+ * refuses a library that does not match -- file times say nothing after a copy to another machine. */
+const char *ldpc_source_hash(void);
 
 #ifdef __cplusplus
 }

@@ -1113,6 +1113,25 @@ def test_random_graphs_engines_agree_with_the_oracle(seed, gpu_device, oracle_mo
     np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
     np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
 
+    # the reference's layered schedule: LDS-resident layered kernel == streaming kernel == oracle (which restates the early-stop
+    # form; a fixed-T run is compared between the two kernels only)
+    if code.H.shape[0] > 1 and int(code.H.sum(axis=1).max()) >= 1:
+        from rcq_decoder import RCQMinSumDecoder
+        lay = RCQMinSumDecoder(code, 3, 8, QP, max_iterations=T, layered=True)
+        le = lay._get_engine(gpu_device)
+        le.set_mode("auto")
+        a = le.decode(x, early_stop=early, want_packed=True)
+        le.set_mode("stream")
+        b = le.decode(x, early_stop=early, want_packed=True)
+        assert torch.equal(a.bits, b.bits) and torch.equal(a.iterations, b.iterations) and torch.equal(a.success, b.success)
+        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.packed_bits, b.packed_bits)
+        if early:
+            ob, op, oi, osucc = oracle_mod.rcq_layered(og, llr, 3, QP, T)
+            np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+            np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+            np.testing.assert_array_equal(a.success.cpu().numpy(), osucc)
+            np.testing.assert_array_equal(a.posterior.cpu().numpy(), op)
+
     basic = BasicMinSumDecoder(code, 0.7)                       # the reference's float64 decoder, resident fp64 kernel
     x64 = torch.from_numpy(llr.astype(np.float64)).to(gpu_device)
     a = both_engines(basic._engine(torch.float64, gpu_device), x64)

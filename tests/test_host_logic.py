@@ -343,8 +343,9 @@ def test_reference_import_lines_work_verbatim():
 
 def test_native_library_staleness_is_decided_by_content_hash(tmp_path, monkeypatch):
     """file times say nothing after a copy to another box.  build_native / load decide by a hash of the
-    sources' CONTENT (plus the compile recipe) stored beside the library; a library without a matching record is stale
-    and is never loaded silently."""
+    sources' CONTENT (plus the compile recipe) EMBEDDED in the library (ldpc_source_hash()); a library that does not
+    carry the hash of the sources on disk is stale and is never loaded silently."""
+    import subprocess
     import _native
     lib_path = os.path.join(PKG, "libldpc_hip.so")
     assert os.path.exists(lib_path), "run __graft_entry__.build() first"
@@ -360,16 +361,22 @@ def test_native_library_staleness_is_decided_by_content_hash(tmp_path, monkeypat
         os.utime(src, (st.st_atime, st.st_mtime))
     # ... a different recipe or different content does
     assert _native.source_hash(defines=("LDPC_X=1",)) != _native.source_hash()
-    fake = tmp_path / "libldpc_hip.so"
-    fake.write_bytes(b"not a library")
-    assert _native.is_stale(str(fake))                                   # no record beside it
-    (tmp_path / "libldpc_hip.so.srchash").write_text("0" * 64 + "\n")
-    assert _native.is_stale(str(fake))                                   # record of other sources
-    (tmp_path / "libldpc_hip.so.srchash").write_text(_native.source_hash() + "\n")
-    assert not _native.is_stale(str(fake))
+    junk = tmp_path / "junk.so"
+    junk.write_bytes(b"not a library")
+    assert _native.built_hash(str(junk)) is None and _native.is_stale(str(junk))
+
+    def fake_lib(name, digest):                                          # a library that CLAIMS to be built from `digest`
+        c = tmp_path / (name + ".c")
+        c.write_text('const char *ldpc_source_hash(void) { return "%s"; }\n' % digest)
+        out = tmp_path / (name + ".so")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(out), str(c)], check=True)
+        return str(out)
+
+    other = fake_lib("other", "0" * 64)
+    assert _native.built_hash(other) == "0" * 64 and _native.is_stale(other)
+    assert not _native.is_stale(fake_lib("same", _native.source_hash()))
     # load() refuses a stale library loudly (no silent use, no compile inside an import)
-    (tmp_path / "libldpc_hip.so.srchash").write_text("0" * 64 + "\n")
-    monkeypatch.setattr(_native, "LIB_PATH", str(fake))
+    monkeypatch.setattr(_native, "LIB_PATH", other)
     monkeypatch.setattr(_native, "_lib", None)
     monkeypatch.delenv("LDPC_HIP_LIB", raising=False)
     with pytest.raises(_native.NativeEngineError, match="stale"):
