@@ -349,8 +349,10 @@ def stream_roofline(engine, workload, g, T, B, llr, reps, copy_gbs, torch):
                                                   "over this kernel's time: the same work as one cn_sweep + one vn_sweep launch"},
                 "posterior_pass": {"ms_per_launch": times["vn"]}}
     ach = bm["cn_sweep"] / (times["cn"] * 1e-3) / 1e9
-    tr, src = traffic_of(db, "cn_sweep", workload, B)
-    return {"bound": "hbm", "kernel": "ldpc::cn_sweep (check-node / CN->VN message sweep, streaming engine)",
+    tr, src = traffic_of(db, "cn_sweep_f4", workload, B)            # fp32 min-sum, check degrees <= 16: the register-held form
+    if tr is None:
+        tr, src = traffic_of(db, "cn_sweep", workload, B)
+    return {"bound": "hbm", "kernel": "ldpc::cn_sweep_f4 / ldpc::cn_sweep (check-node / CN->VN message sweep, streaming engine)",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": ach / copy_gbs if copy_gbs else None,
             "traffic": tr, "traffic_source": src,

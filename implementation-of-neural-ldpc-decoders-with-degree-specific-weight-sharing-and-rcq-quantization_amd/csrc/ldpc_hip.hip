@@ -197,6 +197,30 @@ int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, 
     const int n_wide = d->g->n_wide;                 // > 0: the sweep below skips them, cn_sweep_wide follows
     const T *src = first ? (const T *)w.llrT : (const T *)w.v2c;
     const T *beta_row = (const T *)d->beta + (size_t)it * d->n_beta;
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        // fp32 normalised min-sum on check degrees <= 16: the register-held straight-line form (cn_sweep_f4)
+        if (d->form == LDPC_C2V_NMS && d->g->max_dc <= 16 && !w.c2v_prev) {
+            const int cb4 = (g.m + kWavesPerBlock - 1) / kWavesPerBlock;
+            const dim3 grid4((unsigned)((size_t)w.tiles * cb4));
+            const uint64_t *done4 = use_done ? w.done : nullptr;
+#define LDPC_CF(FIRST_, BPC_, ES_)                                                                                    \
+    hipLaunchKernelGGL((cn_sweep_f4<FIRST_, BPC_, ES_>), grid4, block, 0, s, g, (const float *)src, (float *)w.c2v,     \
+                       (const float *)beta_row, (const int *)d->beta_slot, done4, cb4)
+            switch ((first ? 4 : 0) + (d->beta_per_check ? 2 : 0) + (done4 ? 1 : 0)) {
+            case 0: LDPC_CF(false, false, false); break;
+            case 1: LDPC_CF(false, false, true); break;
+            case 2: LDPC_CF(false, true, false); break;
+            case 3: LDPC_CF(false, true, true); break;
+            case 4: LDPC_CF(true, false, false); break;
+            case 5: LDPC_CF(true, false, true); break;
+            case 6: LDPC_CF(true, true, false); break;
+            default: LDPC_CF(true, true, true); break;
+            }
+#undef LDPC_CF
+            HIP_TRY(hipGetLastError());
+            return LDPC_OK;
+        }
+    }
     const T *oa_row = d->oms_alpha ? (const T *)d->oms_alpha + (size_t)it * d->n_oms_alpha : nullptr;
     const float *thr = d->form == LDPC_C2V_RCQ ? d->thresholds + (size_t)d->q_of_iter[it] * d->n_levels : nullptr;
     const uint64_t *done = use_done ? w.done : nullptr;

@@ -366,6 +366,114 @@ __global__ __launch_bounds__(kBlock) void cn_sweep(GraphDev g, const T *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Check-node sweep, fp32 normalised min-sum, 256-codeword tiles, check degrees <= 16 -- the form the benchmark codes run
+// (BASELINE config 2 on the streaming engine: the north_star's CN->VN sweep).  Same wave mapping and the same values as
+// cn_sweep, written the way cn_sweep_q4 is: one straight-line body per degree, ALL rows of the check requested before the
+// first use and held in registers for both passes (13.5 KB in flight per wave instead of one 1 KB row at a time, no row is
+// read twice, no sign / arg-min masks), and branch-free arithmetic: min1 / min2 by v_med3 (ties make min2 == min1, so
+// "|x| == min1" picks the arg-min edge's output exactly as the first-index arg-min does), the sign product as an XOR of the
+// raw bit patterns, the edge's own sign folded in with one v_bitop3.  BPC (one beta per check): the two scaled magnitudes
+// are formed once per check.  The generic cn_sweep keeps every other case (fp64, RCQ, OMS, wider checks, the saving forward).
+// ------------------------------------------------------------------------------------------
+template <int DC, bool FIRST, bool BPC, bool ES>
+__device__ __forceinline__ void cn_f4_check(const GraphDev &g, int e0, const float *__restrict__ in_base,
+                                            float *__restrict__ out_base, const float *__restrict__ beta_row,
+                                            const int *__restrict__ beta_slot, const Frozen<4> &fz)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    Pack<float, VEC> v[DC];
+#pragma unroll
+    for (int t = 0; t < DC; ++t)
+        v[t] = ld<float, VEC>(FIRST ? in_base + (size_t)g.var_idx[e0 + t] * W : in_base + (size_t)t * W);
+    float m1[VEC], m2[VEC];
+    uint32_t sacc[VEC];
+    float ninf = -inf_of<float>();
+    asm volatile("" : "+v"(ninf));                    // opaque to constant folding: min as ONE v_med3
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) { m1[c] = inf_of<float>(); m2[c] = inf_of<float>(); sacc[c] = 0; }
+#pragma unroll
+    for (int t = 0; t < DC; ++t) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const float a = __builtin_fabsf(v[t].x[c]);
+            sacc[c] ^= __float_as_uint(v[t].x[c]);
+            m2[c] = __builtin_amdgcn_fmed3f(a, m1[c], m2[c]);
+            m1[c] = __builtin_amdgcn_fmed3f(a, m1[c], ninf);
+        }
+    }
+    if (DC == 1) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) m2[c] = m1[c];   // "min2_val = min_val" (neural_2d_decoder.py:181-182)
+    }
+    if constexpr (BPC) {
+        const float b = beta_row[beta_slot[e0]];
+        uint32_t o1[VEC], o2[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const uint32_t par = sacc[c] & 0x80000000u;
+            o1[c] = __float_as_uint(b * m1[c]) ^ par;
+            o2[c] = __float_as_uint(b * m2[c]) ^ par;
+        }
+#pragma unroll
+        for (int t = 0; t < DC; ++t) {
+            Pack<float, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const uint32_t sel = (__builtin_fabsf(v[t].x[c]) == m1[c]) ? o2[c] : o1[c];
+                o.x[c] = __uint_as_float(__builtin_amdgcn_bitop3_b32(sel, __float_as_uint(v[t].x[c]), 0x80000000u, 0x78));   // sel ^ (x & sign)
+            }
+            if constexpr (ES) store_masked<float, VEC>(out_base + (size_t)t * W, o, fz);
+            else st<float, VEC>(out_base + (size_t)t * W, o);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < DC; ++t) {
+            const float b = beta_row[beta_slot[e0 + t]];
+            Pack<float, VEC> o;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const float raw = (__builtin_fabsf(v[t].x[c]) == m1[c]) ? m2[c] : m1[c];
+                const uint32_t flip = (sacc[c] ^ __float_as_uint(v[t].x[c])) & 0x80000000u;       // parity of the OTHER signs
+                o.x[c] = __uint_as_float(__float_as_uint(b * raw) ^ flip);
+            }
+            if constexpr (ES) store_masked<float, VEC>(out_base + (size_t)t * W, o, fz);
+            else st<float, VEC>(out_base + (size_t)t * W, o);
+        }
+    }
+}
+
+#ifndef LDPC_CNF4_WAVES
+#define LDPC_CNF4_WAVES 5          // waves per SIMD the register allocation leaves room for (16 rows x 4 floats are held per lane)
+#endif
+template <bool FIRST, bool BPC, bool ES>
+__global__ __launch_bounds__(kBlock, LDPC_CNF4_WAVES) void cn_sweep_f4(GraphDev g, const float *__restrict__ src, float *__restrict__ c2v_out,
+                                                      const float *__restrict__ beta_row, const int *__restrict__ beta_slot,
+                                                      const uint64_t *__restrict__ done, int check_blocks)
+{
+    constexpr int VEC = 4, W = kWave * VEC;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int tile = uni(blockIdx.x / check_blocks);
+    const int i = uni((blockIdx.x % check_blocks) * kWavesPerBlock + (threadIdx.x >> 6));
+    if (i >= g.m) return;
+    Frozen<VEC> fz;
+    fz.bits = 0;
+    if constexpr (ES) { if (load_frozen<VEC>(done, tile, lane, fz)) return; }
+    const int e0 = uni(g.check_ptr[i]);
+    const int dc = uni(g.check_ptr[i + 1]) - e0;
+    const size_t lane_off = (size_t)lane * VEC;
+    const float *in_base = FIRST ? src + (size_t)tile * g.n * W + lane_off : src + ((size_t)tile * g.E + e0) * W + lane_off;
+    float *out_base = c2v_out + ((size_t)tile * g.E + e0) * W + lane_off;
+#define LDPC_CF_CASE(D) case D: cn_f4_check<D, FIRST, BPC, ES>(g, e0, in_base, out_base, beta_row, beta_slot, fz); break;
+    switch (dc) {
+        LDPC_CF_CASE(1) LDPC_CF_CASE(2) LDPC_CF_CASE(3) LDPC_CF_CASE(4) LDPC_CF_CASE(5) LDPC_CF_CASE(6) LDPC_CF_CASE(7) LDPC_CF_CASE(8)
+        LDPC_CF_CASE(9) LDPC_CF_CASE(10) LDPC_CF_CASE(11) LDPC_CF_CASE(12) LDPC_CF_CASE(13) LDPC_CF_CASE(14) LDPC_CF_CASE(15)
+        LDPC_CF_CASE(16)
+    default: break;                                   // dc == 0: nothing to do; dc > 16: the host does not launch this kernel
+    }
+#undef LDPC_CF_CASE
+}
+
+// ------------------------------------------------------------------------------------------
 // Check-node sweep for WIDE checks (degree > kWideCheck): lanes still run over codewords, but the check's edges are
 // split over the four waves of the block -- wave w streams the rows of its quarter, keeping min1 / min2 / first
 // arg-min / sign parity / zero count of that quarter; the partials meet in LDS, every wave combines the four in

@@ -70,13 +70,15 @@ def main():
                 args = k[k.index("<") + 1:k.rindex(">")].split(", ") if "<" in k else []
                 if prefix == "cn_sweep" and len(args) >= 4 and args[3] != "false":
                     continue
+                if prefix == "cn_sweep_f4" and args and args[0] != "false":       # cn_sweep_f4<FIRST, BPC, ES>
+                    continue
                 if prefix == "vn_sweep" and len(args) >= 4 and args[3] != "false":
                     continue
                 if best is None or v > best:
                     best = v
             return best
 
-        for key in ("cn_sweep", "vn_sweep", "resident_decode", "cn_gather", "cn_sweep_q4", "vn_sweep_q4", "vn_last_rows",
+        for key in ("cn_sweep", "cn_sweep_f4", "vn_sweep", "resident_decode", "cn_gather", "cn_sweep_q4", "vn_sweep_q4", "vn_last_rows",
                     "transpose_in_q4", "transpose_in_v", "layered_lds"):
             v = pick(key)
             if v is not None:
