@@ -932,15 +932,52 @@ template <typename V, typename T> __device__ __forceinline__ void vec_set(V &v, 
 
 constexpr int kRowsVars = 64;
 constexpr int kRowsStride = kRowsVars + 1;
+#ifndef LDPC_ROWS_XCD
+#define LDPC_ROWS_XCD 0              // 1: the variable chunks of a tile are dealt to the XCDs in CONTIGUOUS ranges (workgroups go round-robin
+                                     // over the 8 XCDs, each with its own L2): a caller row is 4n bytes, not a multiple of the 128-byte
+                                     // line, so every chunk boundary splits a line between two workgroups -- on the same XCD the two
+                                     // halves would meet in one L2.  Measured on config 5 (tools/experiments/rows_xcd_round.sh, one
+                                     // box): vn_last_rows 2.20 -> 2.16 ms (noise), transpose_in_q4 1.16 -> 1.31 ms (its tile-row writes
+                                     // lose their order): off.
+#endif
+#ifndef LDPC_ROWS_NT_STORE
+#define LDPC_ROWS_NT_STORE 0         // caller rows with plain (temporal) stores: vn_last_rows 2.16 -> 1.96 ms against non-temporal ones
+                                     // (the 256-byte runs split lines with the neighbouring chunk's; the halves merge in L2)
+#endif
+// blockIdx -> (tile, variable chunk) of the two boundary kernels; the grid is tiles x rows_grid_chunks(var_blocks)
+__host__ __device__ inline int rows_grid_chunks(int var_blocks) { return LDPC_ROWS_XCD ? (var_blocks + 7) / 8 * 8 : var_blocks; }
+__device__ __forceinline__ bool rows_block(int var_blocks, int &tile, int &chunk)
+{
+    const int gc = rows_grid_chunks(var_blocks);
+    tile = uni((int)(blockIdx.x / gc));
+    const int k = uni((int)(blockIdx.x % gc));
+#if LDPC_ROWS_XCD
+    chunk = (k % 8) * (gc / 8) + k / 8;                             // XCD x (= k % 8) owns chunks [x * gc/8, (x + 1) * gc/8)
+#else
+    chunk = k;
+#endif
+    return chunk < var_blocks;
+}
+template <typename V>
+__device__ __forceinline__ void rows_store(V v, V *p)
+{
+#if LDPC_ROWS_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 constexpr int kRowsThreads = 1024;   // 16 waves x 4 variables: the staging tile (66.5 KB) admits two blocks per CU, and the first
                                      // phase needs every wave slot of the CU to keep enough row loads in flight (with 256-thread
                                      // blocks -- 8 waves per CU -- the kernel ran at 3.7 TB/s)
 __host__ __device__ inline size_t vn_rows_stage_bytes() { return (size_t)256 * kRowsStride * sizeof(float); }
 
-template <typename T, int VEC, bool CODES, int ORDER, int DV>
+// PRE: the edge ids of the wave's variables were fetched once with the lanes in parallel (`ev`, lane = position in the wave's
+// CSC range); this variable's are lanes off .. off + DV - 1 -- no dependent scalar load in front of the row loads
+template <typename T, int VEC, bool CODES, int ORDER, int DV, bool PRE = false>
 __device__ __forceinline__ Pack<T, VEC> vn_post_ct(const GraphDev &g, int tile, int j, int s0, int lane,
                                                    const void *__restrict__ c2v, const T *__restrict__ llrT,
-                                                   const Lut<VEC> &lut)
+                                                   const Lut<VEC> &lut, int ev = 0, int off = 0)
 {
     constexpr int W = kWave * VEC;
     const size_t lane_off = (size_t)lane * VEC;
@@ -948,7 +985,7 @@ __device__ __forceinline__ Pack<T, VEC> vn_post_ct(const GraphDev &g, int tile, 
     int e[DV > 0 ? DV : 1];
     Pack<T, VEC> x[DV > 0 ? DV : 1];
 #pragma unroll
-    for (int k = 0; k < DV; ++k) e[k] = g.csc_edge[s0 + k];
+    for (int k = 0; k < DV; ++k) e[k] = PRE ? __builtin_amdgcn_readlane(ev, off + k) : g.csc_edge[s0 + k];
 #pragma unroll
     for (int k = 0; k < DV; ++k) x[k] = load_c2v<T, VEC, CODES>(c2v, (tileE + e[k]) * W + lane_off, lut);
     const Pack<T, VEC> l = ld<T, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
@@ -985,8 +1022,9 @@ __global__ __launch_bounds__(kRowsThreads, 8) void vn_last_rows(GraphDev g, cons
         __syncthreads();
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int tile = uni(blockIdx.x / var_blocks);
-    const int j0 = uni((blockIdx.x % var_blocks) * kRowsVars);
+    int tile, chunk;
+    if (!rows_block(var_blocks, tile, chunk)) return;               // block-uniform (padding blocks of the XCD-contiguous grid)
+    const int j0 = chunk * kRowsVars;
 
     Frozen<VEC> fz;
     load_frozen<VEC>(done, tile, lane, fz);
@@ -1000,28 +1038,49 @@ __global__ __launch_bounds__(kRowsThreads, 8) void vn_last_rows(GraphDev g, cons
             lut.off[c] = q_of_iter[it > 0 ? it - 1 : 0] * lut_stride;
         }
     }
-    for (int u = 0; u < kPerWave; ++u) {
+    // index data of the wave's kPerWave variables, fetched ONCE with the lanes in parallel (as vn_sweep_q4): var_ptr[jbase ..
+    // jbase + kPerWave] -> CSC edge ids; per variable these were three dependent round trips in front of the row loads
+    const int jbase = j0 + wave * kPerWave;
+    const int nv = max(0, min(kPerWave, g.n - jbase));
+    const int vp = g.var_ptr[min(jbase + min(lane, kPerWave), g.n)];
+    const int s_base = __builtin_amdgcn_readfirstlane(vp);
+    const int n_edges = __builtin_amdgcn_readlane(vp, nv) - s_base;
+    const bool pre = n_edges <= kWave;                             // degrees <= 8 always qualify (4 x 8 edges); else per-variable loads
+    int ev = 0;
+    if (pre && lane < n_edges) ev = g.csc_edge[s_base + lane];
+    for (int u = 0; u < nv; ++u) {
         const int jj = wave * kPerWave + u, j = j0 + jj;
-        if (j >= g.n) break;                                        // wave-uniform
-        const int s0 = uni(g.var_ptr[j]);
-        const int dv = uni(g.var_ptr[j + 1]) - s0;
+        const int s0 = __builtin_amdgcn_readlane(vp, u);
+        const int dv = __builtin_amdgcn_readlane(vp, u + 1) - s0;
         Pack<float, VEC> post;
-#define LDPC_VP_CASE(D) case D: post = vn_post_ct<float, VEC, CODES, 0, D>(g, tile, j, s0, lane, c2v, llrT, lut); break;
-        switch (dv) {
-            LDPC_VP_CASE(0) LDPC_VP_CASE(1) LDPC_VP_CASE(2) LDPC_VP_CASE(3) LDPC_VP_CASE(4)
-            LDPC_VP_CASE(5) LDPC_VP_CASE(6) LDPC_VP_CASE(7) LDPC_VP_CASE(8)
-        default: {
+        auto generic_post = [&]() {                                 // degree > 8: run-time sums, operands re-fetched (L1 / L2 hits)
             const size_t lane_off = (size_t)lane * VEC, tileE = (size_t)tile * g.E;
             auto fetch = [&](int k) {
                 return load_c2v<float, VEC, CODES>(c2v, (tileE + g.csc_edge[s0 + k]) * W + lane_off, lut);
             };
-            post = sum_rt<0, float, VEC>(dv, fetch);
+            Pack<float, VEC> r = sum_rt<0, float, VEC>(dv, fetch);
             const Pack<float, VEC> l = ld<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + lane_off);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) post.x[c] = l.x[c] + post.x[c];
-        }
-        }
+            for (int c = 0; c < VEC; ++c) r.x[c] = l.x[c] + r.x[c];
+            return r;
+        };
+        if (pre) {
+#define LDPC_VPP_CASE(D) case D: post = vn_post_ct<float, VEC, CODES, 0, D, true>(g, tile, j, s0, lane, c2v, llrT, lut, ev, s0 - s_base); break;
+            switch (dv) {
+                LDPC_VPP_CASE(0) LDPC_VPP_CASE(1) LDPC_VPP_CASE(2) LDPC_VPP_CASE(3) LDPC_VPP_CASE(4)
+                LDPC_VPP_CASE(5) LDPC_VPP_CASE(6) LDPC_VPP_CASE(7) LDPC_VPP_CASE(8)
+            default: post = generic_post();
+            }
+#undef LDPC_VPP_CASE
+        } else {
+#define LDPC_VP_CASE(D) case D: post = vn_post_ct<float, VEC, CODES, 0, D>(g, tile, j, s0, lane, c2v, llrT, lut); break;
+            switch (dv) {
+                LDPC_VP_CASE(0) LDPC_VP_CASE(1) LDPC_VP_CASE(2) LDPC_VP_CASE(3) LDPC_VP_CASE(4)
+                LDPC_VP_CASE(5) LDPC_VP_CASE(6) LDPC_VP_CASE(7) LDPC_VP_CASE(8)
+            default: post = generic_post();
+            }
 #undef LDPC_VP_CASE
+        }
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const uint64_t mask = __ballot(post.x[c] < 0.0f);        // the syndrome pass reads the ballot words
@@ -1051,8 +1110,8 @@ __global__ __launch_bounds__(kRowsThreads, 8) void vn_last_rows(GraphDev g, cons
             vec_set<IV, int>(d, q, src[q] < 0.0f ? 1 : 0);
         }
         const size_t o = (size_t)b * g.n + j0 + jq;
-        if (posterior) __builtin_nontemporal_store(v, reinterpret_cast<FV *>(posterior + o));
-        if (bits) __builtin_nontemporal_store(d, reinterpret_cast<IV *>(bits + o));
+        if (posterior) rows_store(v, reinterpret_cast<FV *>(posterior + o));
+        if (bits) rows_store(d, reinterpret_cast<IV *>(bits + o));
     }
 }
 
@@ -1635,8 +1694,9 @@ __global__ __launch_bounds__(kRowsThreads, 8) void transpose_in_q4(GraphDev g, c
     float *stage = rows_smem;
     typedef float F4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int tile = uni(blockIdx.x / var_blocks);
-    const int j0 = uni((blockIdx.x % var_blocks) * kRowsVars);
+    int tile, chunk;
+    if (!rows_block(var_blocks, tile, chunk)) return;               // block-uniform
+    const int j0 = chunk * kRowsVars;
     {
         const int jq = (threadIdx.x % kTpr) * 4, l = threadIdx.x / kTpr;       // codeword 4 * l + c of the tile
         F4 v[VEC];

@@ -672,24 +672,29 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
                                               int tid, int nt, const ParScatter ps = ParScatter{})
 {
     const int n = pl.n, n_hi = pl.n_hi;
-    const uint2 zero2 = make_uint2(0, 0);
+    // Plan loads are UNCONDITIONAL with clamped indices (a lane past the end re-reads the last entry, a variable of degree <= 4
+    // reads the last `hi` entry: same cache lines, values unused): with a fixed number of loads per round the compiler waits for
+    // the CURRENT variable's entries with vmcnt(3) and leaves the next one's in flight -- behind `if (q < n_hi)` it could not
+    // count them and drained the queue (vmcnt(0)) right after issuing the prefetch, every round.
+    const int hi_last = (n_hi > 0 ? n_hi : 1) - 1;
     int q = tid;
     unsigned meta = 0;
-    uint2 plo = zero2, phi = zero2;                      // packed offsets, unpacked at the point of use
+    uint2 plo = make_uint2(0, 0), phi = make_uint2(0, 0);           // packed offsets, unpacked at the point of use
     if (q < n) {
         meta = pl.vmeta[q];
         plo = pl.vslot_lo[q];
-        if (q < n_hi) phi = pl.vslot_hi[q];
+        phi = pl.vslot_hi[min(q, hi_last)];
     }
     while (q < n) {
         const int qn = q + nt;
-        unsigned metan = 0;
-        uint2 plon = zero2, phin = zero2;
+        unsigned metan;
+        uint2 plon, phin;
 #if !LDPC_RES_NO_PLAN_PREFETCH                        // tuning builds with more waves per SIMD trade the prefetch for registers
-        if (qn < n) {
-            metan = pl.vmeta[qn];
-            plon = pl.vslot_lo[qn];
-            if (qn < n_hi) phin = pl.vslot_hi[qn];
+        {
+            const int qc = min(qn, n - 1);
+            metan = pl.vmeta[qc];
+            plon = pl.vslot_lo[qc];
+            phin = pl.vslot_hi[min(qc, hi_last)];
         }
 #endif
         const int dv = (int)(meta & 0xffu);
@@ -712,10 +717,11 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
         res_var_dispatch<G, MODE, T>(smem, llr_s, bits_s, q, dv, slo, shi, a, emask, ps);
 #endif
 #if LDPC_RES_NO_PLAN_PREFETCH
-        if (qn < n) {
-            metan = pl.vmeta[qn];
-            plon = pl.vslot_lo[qn];
-            if (qn < n_hi) phin = pl.vslot_hi[qn];
+        {
+            const int qc = min(qn, n - 1);
+            metan = pl.vmeta[qc];
+            plon = pl.vslot_lo[qc];
+            phin = pl.vslot_hi[min(qc, hi_last)];
         }
 #endif
         q = qn; meta = metan; plo = plon; phi = phin;
