@@ -302,7 +302,7 @@ int launch_vn(const ldpc_decoder *d, const Workspace &w, int it, bool last, bool
             const int lut_cur = codes ? d->q_of_iter[row] * lut_stride : 0;
             const size_t shmem = vn_rows_stage_bytes() + (size_t)lut_total * sizeof(float);
             const int vb = (g.n + kRowsVars - 1) / kRowsVars;
-            const dim3 grid((unsigned)((size_t)w.tiles * rows_grid_chunks(vb))), block(kRowsThreads);
+            const dim3 grid((unsigned)((size_t)w.tiles * rows_grid_chunks(vb, LDPC_ROWS_XCD != 0))), block(kRowsThreads);
             const uint64_t *done = use_done ? w.done : nullptr;
 #define LDPC_VR(CODES)                                                                                          \
     do {                                                                                                        \
@@ -562,7 +562,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     do {                                                                                                             \
         auto kfn = transpose_in_q4<NL_>;                                                                             \
         if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                   \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)((size_t)w.tiles * rows_grid_chunks(vb))), dim3(kRowsThreads), vn_rows_stage_bytes(), s, g, \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)((size_t)w.tiles * rows_grid_chunks(vb, false))), dim3(kRowsThreads), vn_rows_stage_bytes(), s, g, \
                            (const float *)llr, (float *)w.llrT, (uint8_t *)w.v2c, beta0, (const int *)d->beta_slot, \
                            thr0, d->n_levels, (long long)batch, vb);                                                \
     } while (0)

@@ -933,29 +933,27 @@ template <typename V, typename T> __device__ __forceinline__ void vec_set(V &v, 
 constexpr int kRowsVars = 64;
 constexpr int kRowsStride = kRowsVars + 1;
 #ifndef LDPC_ROWS_XCD
-#define LDPC_ROWS_XCD 0              // 1: the variable chunks of a tile are dealt to the XCDs in CONTIGUOUS ranges (workgroups go round-robin
-                                     // over the 8 XCDs, each with its own L2): a caller row is 4n bytes, not a multiple of the 128-byte
-                                     // line, so every chunk boundary splits a line between two workgroups -- on the same XCD the two
-                                     // halves would meet in one L2.  Measured on config 5 (tools/experiments/rows_xcd_round.sh, one
-                                     // box): vn_last_rows 2.20 -> 2.16 ms (noise), transpose_in_q4 1.16 -> 1.31 ms (its tile-row writes
-                                     // lose their order): off.
+#define LDPC_ROWS_XCD 1              // vn_last_rows: the variable chunks of a tile are dealt to the XCDs in CONTIGUOUS ranges (workgroups go
+                                     // round-robin over the 8 XCDs, each with its own L2): a caller row is 4n bytes, not a multiple of the
+                                     // 128-byte line, so every chunk boundary splits a line between two workgroups -- on the same XCD the
+                                     // two halves meet in one L2, written with plain (temporal) stores.  Config 5, per launch
+                                     // (tools/experiments/rows_xcd_round.sh and the r03 profiles): plain order + non-temporal 2.20 ms,
+                                     // XCD-contiguous + non-temporal 2.16, XCD-contiguous + temporal 1.96, plain order + temporal 2.40.
+                                     // transpose_in_q4 keeps the plain order (1.16 ms; XCD-contiguous 1.31: its tile-row writes lose
+                                     // their order).
 #endif
 #ifndef LDPC_ROWS_NT_STORE
-#define LDPC_ROWS_NT_STORE 0         // caller rows with plain (temporal) stores: vn_last_rows 2.16 -> 1.96 ms against non-temporal ones
-                                     // (the 256-byte runs split lines with the neighbouring chunk's; the halves merge in L2)
+#define LDPC_ROWS_NT_STORE 0         // caller rows of vn_last_rows with non-temporal stores (A/B knob; see above)
 #endif
-// blockIdx -> (tile, variable chunk) of the two boundary kernels; the grid is tiles x rows_grid_chunks(var_blocks)
-__host__ __device__ inline int rows_grid_chunks(int var_blocks) { return LDPC_ROWS_XCD ? (var_blocks + 7) / 8 * 8 : var_blocks; }
+// blockIdx -> (tile, variable chunk) of the two boundary kernels; the grid is tiles x rows_grid_chunks(var_blocks, xcd)
+__host__ __device__ inline int rows_grid_chunks(int var_blocks, bool xcd) { return xcd ? (var_blocks + 7) / 8 * 8 : var_blocks; }
+template <bool XCD>
 __device__ __forceinline__ bool rows_block(int var_blocks, int &tile, int &chunk)
 {
-    const int gc = rows_grid_chunks(var_blocks);
+    const int gc = rows_grid_chunks(var_blocks, XCD);
     tile = uni((int)(blockIdx.x / gc));
     const int k = uni((int)(blockIdx.x % gc));
-#if LDPC_ROWS_XCD
-    chunk = (k % 8) * (gc / 8) + k / 8;                             // XCD x (= k % 8) owns chunks [x * gc/8, (x + 1) * gc/8)
-#else
-    chunk = k;
-#endif
+    chunk = XCD ? (k % 8) * (gc / 8) + k / 8 : k;                   // XCD x (= k % 8) owns chunks [x * gc/8, (x + 1) * gc/8)
     return chunk < var_blocks;
 }
 template <typename V>
@@ -1023,7 +1021,7 @@ __global__ __launch_bounds__(kRowsThreads, 8) void vn_last_rows(GraphDev g, cons
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     int tile, chunk;
-    if (!rows_block(var_blocks, tile, chunk)) return;               // block-uniform (padding blocks of the XCD-contiguous grid)
+    if (!rows_block<LDPC_ROWS_XCD != 0>(var_blocks, tile, chunk)) return;   // block-uniform (padding blocks of the XCD-contiguous grid)
     const int j0 = chunk * kRowsVars;
 
     Frozen<VEC> fz;
@@ -1695,7 +1693,7 @@ __global__ __launch_bounds__(kRowsThreads, 8) void transpose_in_q4(GraphDev g, c
     typedef float F4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     int tile, chunk;
-    if (!rows_block(var_blocks, tile, chunk)) return;               // block-uniform
+    if (!rows_block<false>(var_blocks, tile, chunk)) return;        // plain chunk order (see LDPC_ROWS_XCD)
     const int j0 = chunk * kRowsVars;
     {
         const int jq = (threadIdx.x % kTpr) * 4, l = threadIdx.x / kTpr;       // codeword 4 * l + c of the tile

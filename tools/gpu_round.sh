@@ -30,6 +30,8 @@ bench)
   LDPC_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --warmup 1 --leg-steps 2 --config5-total 16384 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err || echo "2-rank rehearsal failed" >> $O/errors.log
   LDPC_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --workload wrcq_dvbs2 --strong --batch 16384 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_wrcq_strong.json 2> $O/bench_2rank_gloo_wrcq.err || echo "2-rank wrcq rehearsal failed" >> $O/errors.log
   timeout -k 10 600 python bench.py --gpus 1 --force-dist --steps 5 --warmup 2 --leg-steps 2 --no-cpu-baseline --no-stream-leg > $O/bench_1rank_rccl.json 2> $O/bench_1rank_rccl.err || echo "1-rank RCCL failed" >> $O/errors.log
+  # the driver's own launch form for N > 1 (torch.distributed.run; gloo stands in for RCCL on this one GPU)
+  LDPC_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --leg-steps 1 --config5-total 8192 --no-cpu-baseline --no-stream-leg 2> $O/bench_2rank_torchrun.err | grep '^{' > $O/bench_2rank_torchrun.json || echo "2-rank torchrun rehearsal failed" >> $O/errors.log
   timeout -k 10 120 python tools/time_layered.py > $O/layered.jsonl 2> $O/layered.err || echo "layered timing failed" >> $O/errors.log
   echo "bench lines done"; cat $O/bench_*.json | cut -c1-260
   ;;
