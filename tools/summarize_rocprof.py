@@ -25,7 +25,7 @@ def short(name):
 def main():
     tag, workload, stats_dir = sys.argv[1:4]
     os.makedirs(PROF, exist_ok=True)
-    f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # newest run
     rows = list(csv.DictReader(open(f)))
     out = os.path.join(PROF, f"{tag}_{workload}_kernel_stats.csv")
     with open(out, "w", newline="") as fh:
@@ -37,7 +37,7 @@ def main():
     if len(sys.argv) >= 6:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for d in sys.argv[4:6]:
-            f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+            f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
             for r in csv.DictReader(open(f)):
                 if "ldpc::" in r["Kernel_Name"]:
                     agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
