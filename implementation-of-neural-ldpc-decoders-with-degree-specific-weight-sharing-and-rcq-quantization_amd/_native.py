@@ -120,7 +120,7 @@ PRODUCT_EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info",
                    "ldpc_decode", "ldpc_last_error", "ldpc_abi_version", "ldpc_source_hash",
                    "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
 # ... and the measurement / test hooks of include/ldpc_hip_debug.h (bench.py's per-kernel timing, the tests' state dumps)
-DEBUG_EXPORTS = ("ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_debug_resident_c2v")
+DEBUG_EXPORTS = ("ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_debug_resident_c2v", "ldpc_debug_key4")
 EXPORTS = PRODUCT_EXPORTS + DEBUG_EXPORTS
 
 _lib = None
@@ -172,6 +172,8 @@ def load():
         lib.ldpc_debug_sweep.argtypes = [vp, i64, i32, i32, vp, C.c_size_t, vp]
         lib.ldpc_debug_workspace_layout.restype = C.c_int
         lib.ldpc_debug_workspace_layout.argtypes = [vp, i64, vp]
+        lib.ldpc_debug_key4.restype = C.c_int
+        lib.ldpc_debug_key4.argtypes = [vp, i64, C.c_float, vp, vp, vp, vp]
         lib.ldpc_debug_resident_c2v.restype = C.c_int
         lib.ldpc_debug_resident_c2v.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
         lib.ldpc_train_saved_bytes.restype = C.c_size_t

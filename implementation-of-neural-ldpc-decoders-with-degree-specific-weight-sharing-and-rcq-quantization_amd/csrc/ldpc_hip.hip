@@ -111,6 +111,7 @@ struct ldpc_decoder {
     // flooding RCQ decoders on graphs with variable degree <= 8
     bool gat_ok = false;
     bool pair_ok = false;          // RCQ code-pair form (vn_sweep_q / cn_sweep_q): one beta per check, sorted thresholds
+    bool key_float4 = false;       // ... with 4 levels and every threshold 1.. in [2^-50, 2^50]: the float form of the key (kKeyFloat4)
     int4 *gat_meta = nullptr;      // [E + 1]
     int *gat_nbr = nullptr;        // [sum dv(dv-1) + 8]
     // LDS-resident layered decode (ldpc_layered.hip): LDPC_SCHED_LAYERED_REF on codes whose posteriors fit LDS
@@ -428,10 +429,11 @@ int launch_vn_q(const ldpc_decoder *d, const Workspace &w, int it, bool use_done
     hipLaunchKernelGGL((vn_sweep_q4<NL_, false, LDPC_VNQ_VPW, true>), grid4, block, 0, s, g, (const uint8_t *)w.c2v,     \
                        (const float *)w.llrT, (uint8_t *)w.v2c, alpha_row, (const int *)d->alpha_slot, lut_cur,         \
                        lut_entries, beta_next, (const int *)d->beta_slot, thr_next, d->n_levels, w.bitsT, done, vb4)
-        if (d->n_levels == 4) LDPC_VQI(4); else LDPC_VQI(0);
+        if (d->key_float4) LDPC_VQI(kKeyFloat4); else if (d->n_levels == 4) LDPC_VQI(4); else LDPC_VQI(0);
 #undef LDPC_VQI
     } else if (pair_q4<VEC>(d)) {
-        if (d->n_levels == 4) { if (done) LDPC_VQ4(4, true); else LDPC_VQ4(4, false); }
+        if (d->key_float4) { if (done) LDPC_VQ4(kKeyFloat4, true); else LDPC_VQ4(kKeyFloat4, false); }
+        else if (d->n_levels == 4) { if (done) LDPC_VQ4(4, true); else LDPC_VQ4(4, false); }
         else { if (done) LDPC_VQ4(0, true); else LDPC_VQ4(0, false); }
     }
     else if (d->n_levels == 4) LDPC_VQ(4); else LDPC_VQ(0);
@@ -566,7 +568,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                            (const float *)llr, (float *)w.llrT, (uint8_t *)w.v2c, beta0, (const int *)d->beta_slot, \
                            thr0, d->n_levels, (long long)batch, vb);                                                \
     } while (0)
-            if (d->n_levels == 4) LDPC_TIQ(4); else LDPC_TIQ(0);
+            if (d->key_float4) LDPC_TIQ(kKeyFloat4); else if (d->n_levels == 4) LDPC_TIQ(4); else LDPC_TIQ(0);
 #undef LDPC_TIQ
             fused_init = true;
         }
@@ -1468,6 +1470,13 @@ static int decoder_create_impl(ldpc_decoder **out, const ldpc_graph *g, const ld
                 if (!(t > 0.0f) || (k > 1 && t < desc->thresholds[(size_t)q * d->n_levels + k - 1])) { sorted = false; break; }
             }
         d->pair_ok = sorted;
+        bool in_range = sorted && d->n_levels == 4 && LDPC_KEY_FLOAT != 0;
+        for (int q = 0; q < d->n_quant && in_range; ++q)
+            for (int k = 1; k < d->n_levels; ++k) {
+                const float t = desc->thresholds[(size_t)q * d->n_levels + k];
+                if (!(t >= 0x1p-50f && t <= 0x1p50f)) in_range = false;
+            }
+        d->key_float4 = in_range;
     }
     resident_table_flags(d, desc->alpha, d->form == LDPC_C2V_RCQ ? desc->thresholds : nullptr);
     if (!rc && d->schedule == LDPC_SCHED_FLOODING) rc = build_resident_plan(d, desc);
@@ -1755,6 +1764,17 @@ int ldpc_backward(const ldpc_decoder *d, const void *saved, size_t saved_bytes, 
                                 (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, (float *)grad_llr, w, s);
     return backward_impl<4>(d, (const char *)saved, (const float *)llr, batch, iterations, (const float *)grad_posterior,
                             (float *)grad_beta, (float *)grad_alpha, (float *)grad_oms_alpha, (float *)grad_llr, w, s);
+}
+
+int ldpc_debug_key4(const float *values, int64_t count, float beta, const float thresholds4[4], uint8_t *keys_float,
+                    uint8_t *keys_compare, void *stream)
+{
+    if (!values || !thresholds4 || !keys_float || !keys_compare || count <= 0) return fail(LDPC_ERR_ARG, "bad argument");
+    const long long pairs = (count + 1) / 2;
+    hipLaunchKernelGGL(debug_key4, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, values,
+                       (long long)count, beta, thresholds4, keys_float, keys_compare);
+    HIP_TRY(hipGetLastError());
+    return LDPC_OK;
 }
 
 int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t out8[8])

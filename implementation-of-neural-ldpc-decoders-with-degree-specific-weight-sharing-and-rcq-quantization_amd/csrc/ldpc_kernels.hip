@@ -1511,6 +1511,82 @@ __device__ __forceinline__ unsigned key_of(float val, float b, const unsigned (&
     return key;
 }
 
+// Float form of the same key for 4 levels (NL == kKeyFloat4): key = [m > 0] + [m >= t1] + [m >= t2] + [m >= t3] with every
+// bracket an exact 0.0f / 1.0f from ONE fast instruction.  On gfx950 v_add/v_mul/v_fma_f32 with VGPR operands (abs / neg /
+// clamp modifiers included) issue in ~2.2 cycles when two or more waves share the SIMD, compares, add-with-carry, min/max,
+// shifts and everything with an SGPR operand in ~4.2 (tools/probes/valu_issue_probe.hip, profiles/r03_valu_issue_probe.txt):
+// the compare chain above costs 9 slow instructions per value, this form 2 packed + 4 fast + 3 adds.
+//   G = (b * v) * K, K = 2^75 (power of two: exact, also for a subnormal product; a product >= 2^53 becomes inf, which passes
+//   every bracket as it must);  [m >= t] = clamp(|G| - prev(t) * K): m >= t  <=>  m > prev(t), and then the difference is at
+//   least ulp(prev(t)) * K >= 1 (the host admits thresholds in [2^-50, 2^50] to this form), else it is <= 0;
+//   [m > 0] = clamp(|G| * K) (m >= 2^-149 -> >= 2);  NaN -> every bracket 0 (DX10 clamp), as the compare form's squash.
+constexpr int kKeyFloat4 = 104;
+#ifndef LDPC_KEY_FLOAT
+#define LDPC_KEY_FLOAT 1          // 0: 4-level decoders keep the compare chain (A/B builds)
+#endif
+struct KeyTab {
+    unsigned tb[8];               // compare forms: threshold bit patterns (NaN padding)
+    float K, c1, c2, c3;          // float form: 2^75 and prev(t_q) * 2^75
+};
+template <int NL>
+__device__ __forceinline__ void key_tab_init(KeyTab &kt, const float *__restrict__ thr, int n_levels)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kt.tb[q] = (q < n_levels) ? __float_as_uint(thr[q]) : 0x7fc00000u;
+    kt.K = 0x1p75f; kt.c1 = kt.c2 = kt.c3 = 0.0f;
+    if constexpr (NL == kKeyFloat4) {
+        kt.c1 = __uint_as_float(kt.tb[1] - 1u) * 0x1p75f;
+        kt.c2 = __uint_as_float(kt.tb[2] - 1u) * 0x1p75f;
+        kt.c3 = __uint_as_float(kt.tb[3] - 1u) * 0x1p75f;
+    }
+}
+// keys of a codeword pair's scaled values G into bytes B0 / B0 + 1 of `keys`: the eight brackets, their sums (exact small
+// integers) and the two float -> byte insertions as ONE block, so that the scheduler cannot spread the fourteen temporaries of
+// a degree-8 variable's sixteen values over the whole body (it did: 170 VGPRs)
+template <int B0>
+__device__ __forceinline__ unsigned key_pair4(f32x2 G, const KeyTab &kt, unsigned keys)
+{
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    asm("v_mul_f32_e64 %1, |%9|, %11 clamp\n\t"
+        "v_add_f32_e64 %2, |%9|, -%12 clamp\n\t"
+        "v_add_f32_e64 %3, |%9|, -%13 clamp\n\t"
+        "v_add_f32_e64 %4, |%9|, -%14 clamp\n\t"
+        "v_mul_f32_e64 %5, |%10|, %11 clamp\n\t"
+        "v_add_f32_e64 %6, |%10|, -%12 clamp\n\t"
+        "v_add_f32_e64 %7, |%10|, -%13 clamp\n\t"
+        "v_add_f32_e64 %8, |%10|, -%14 clamp\n\t"
+        "v_add_f32_e32 %1, %1, %2\n\t"
+        "v_add_f32_e32 %3, %3, %4\n\t"
+        "v_add_f32_e32 %5, %5, %6\n\t"
+        "v_add_f32_e32 %7, %7, %8\n\t"
+        "v_add_f32_e32 %1, %1, %3\n\t"
+        "v_add_f32_e32 %5, %5, %7\n\t"
+        "v_cvt_pk_u8_f32 %0, %1, %15, %0\n\t"
+        "v_cvt_pk_u8_f32 %0, %5, %16, %0"
+        : "+v"(keys), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+        : "v"(G.x), "v"(G.y), "v"(kt.K), "v"(kt.c1), "v"(kt.c2), "v"(kt.c3), "n"(B0), "n"(B0 + 1));
+    return keys;
+}
+
+// test hook (ldpc_debug_key4): both key forms on arbitrary values, one value pair per thread
+__global__ void debug_key4(const float *__restrict__ vals, long long n, float b, const float *__restrict__ thr,
+                           uint8_t *__restrict__ out_float, uint8_t *__restrict__ out_compare)
+{
+    KeyTab kt;
+    key_tab_init<kKeyFloat4>(kt, thr, 4);
+    const long long i = 2 * ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const f32x2 v = {vals[i], i + 1 < n ? vals[i + 1] : 0.0f};
+    const f32x2 G = (v * b) * kt.K;
+    const unsigned kf = key_pair4<0>(G, kt, 0u);
+    out_float[i] = (uint8_t)(kf & 0xffu);
+    out_compare[i] = (uint8_t)key_of<4>(v.x, b, kt.tb);
+    if (i + 1 < n) {
+        out_float[i + 1] = (uint8_t)((kf >> 8) & 0xffu);
+        out_compare[i + 1] = (uint8_t)key_of<4>(v.y, b, kt.tb);
+    }
+}
+
 // the LUT is the only LDS object of vn_sweep_q4 (it starts at LDS address 0): read it by absolute byte offset
 __device__ __forceinline__ float lut_at(unsigned byte_off)
 {
@@ -1523,7 +1599,7 @@ template <int NL, bool ES, bool INIT, int DV>
 __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, int off, int lane,
                                            const uint8_t *__restrict__ c2v, const float *__restrict__ llrT,
                                            uint8_t *__restrict__ v2c, float a, int ev, float bv,
-                                           const unsigned (&tb)[8], uint64_t *__restrict__ bitsT, const Frozen<4> &fz,
+                                           const KeyTab &kt, uint64_t *__restrict__ bitsT, const Frozen<4> &fz,
                                            const Pack<float, 4> *l_ext = nullptr)
 {
     constexpr int VEC = 4, W = kWave * VEC;
@@ -1583,13 +1659,18 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) {
-            const unsigned k0 = key_of<NL>(v[k].x, bb[k], tb), k1 = key_of<NL>(v[k].y, bb[k], tb);
             const unsigned u0 = __float_as_uint(v[k].x), u1 = __float_as_uint(v[k].y);
+            if constexpr (NL == kKeyFloat4) {
+                const f32x2 G = (v[k] * bb[k]) * kt.K;                                      // two packed multiplies per codeword pair
+                keys[k] = h == 0 ? key_pair4<0>(G, kt, keys[k]) : key_pair4<2>(G, kt, keys[k]);     // bytes 2h, 2h + 1
+            } else {
+                const unsigned k0 = key_of<NL>(v[k].x, bb[k], kt.tb), k1 = key_of<NL>(v[k].y, bb[k], kt.tb);
+                if (h == 0) keys[k] = k0 | (k1 << 8);
+                else keys[k] |= (k0 << 16) | (k1 << 24);
+            }
             if (h == 0) {
-                keys[k] = k0 | (k1 << 8);
                 sgns[k] = __builtin_amdgcn_perm(u1, u0, 0x0c0c0703u);                       // byte 0 = top of u0, byte 1 = top of u1
             } else {
-                keys[k] |= (k0 << 16) | (k1 << 24);
                 sgns[k] = __builtin_amdgcn_perm(u0, sgns[k], 0x0c070100u);
                 sgns[k] = __builtin_amdgcn_perm(u1, sgns[k], 0x07020100u);
             }
@@ -1606,8 +1687,11 @@ __device__ __forceinline__ void vn_q4_body(const GraphDev &g, int tile, int j, i
 #ifndef LDPC_VNQ_VPW
 #define LDPC_VNQ_VPW 8
 #endif
+#ifndef LDPC_VNQ_WAVES
+#define LDPC_VNQ_WAVES 8          // waves per SIMD the register allocation must leave room for
+#endif
 template <int NL, bool ES, int VPW, bool INIT = false>
-__global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t *__restrict__ c2v,
+__global__ __launch_bounds__(kBlock, LDPC_VNQ_WAVES) void vn_sweep_q4(GraphDev g, const uint8_t *__restrict__ c2v,
                                                       const float *__restrict__ llrT, uint8_t *__restrict__ v2c,
                                                       const float *__restrict__ alpha_row, const int *__restrict__ alpha_slot,
                                                       const float *__restrict__ lut_cur, int lut_entries,
@@ -1630,9 +1714,8 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
     Frozen<VEC> fz;
     fz.bits = 0;
     if constexpr (ES) { if (load_frozen<VEC>(done, tile, lane, fz)) return; }
-    unsigned tb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tb[q] = (q < n_levels) ? __float_as_uint(thr_next[q]) : 0x7fc00000u;
+    KeyTab kt;
+    key_tab_init<NL>(kt, thr_next, n_levels);
     // Index data of the wave's VPW variables, fetched ONCE with the lanes in parallel (degrees <= 8: at most 64 edges):
     // var_ptr[jbase .. jbase + VPW] -> CSC edge ids -> beta slots -> betas, alpha slots -> alphas.  Per variable these would
     // be three dependent scalar round trips in front of the row loads; here the variables only pick lanes (v_readlane).
@@ -1655,7 +1738,7 @@ __global__ __launch_bounds__(kBlock) void vn_sweep_q4(GraphDev g, const uint8_t 
         const int dv = __builtin_amdgcn_readlane(vp, u + 1) - s0;
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), u));
 #define LDPC_VQ_CASE(D) \
-    case D: vn_q4_body<NL, ES, INIT, D>(g, tile, j, s0 - s_base, lane, c2v, llrT, v2c, a, ev, bv, tb, bitsT, fz); break;
+    case D: vn_q4_body<NL, ES, INIT, D>(g, tile, j, s0 - s_base, lane, c2v, llrT, v2c, a, ev, bv, kt, bitsT, fz); break;
         switch (dv) {
             LDPC_VQ_CASE(0) LDPC_VQ_CASE(1) LDPC_VQ_CASE(2) LDPC_VQ_CASE(3) LDPC_VQ_CASE(4)
             LDPC_VQ_CASE(5) LDPC_VQ_CASE(6) LDPC_VQ_CASE(7) LDPC_VQ_CASE(8)
@@ -1714,9 +1797,8 @@ __global__ __launch_bounds__(kRowsThreads, 8) void transpose_in_q4(GraphDev g, c
     __syncthreads();
     const int jbase = j0 + wave * kPerWave;
     if (jbase >= g.n) return;
-    unsigned tb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tb[q] = (q < n_levels) ? __float_as_uint(thr0[q]) : 0x7fc00000u;
+    KeyTab kt;
+    key_tab_init<NL>(kt, thr0, n_levels);
     // index data of the wave's variables, fetched once with the lanes in parallel (as vn_sweep_q4; <= 32 edges here)
     const int nv = min(kPerWave, g.n - jbase);
     const int vp = g.var_ptr[min(jbase + min(lane, kPerWave), g.n)];
@@ -1740,7 +1822,7 @@ __global__ __launch_bounds__(kRowsThreads, 8) void transpose_in_q4(GraphDev g, c
         for (int c = 0; c < VEC; ++c) l.x[c] = stage[(size_t)(c * kWave + lane) * kRowsStride + jj];
         st<float, VEC>(llrT + ((size_t)tile * g.n + j) * W + (size_t)lane * VEC, l);
 #define LDPC_TQ_CASE(D) \
-    case D: vn_q4_body<NL, false, true, D>(g, tile, j, s0 - s_base, lane, nullptr, nullptr, v2c, 0.0f, ev, bv, tb, nullptr, fz, &l); break;
+    case D: vn_q4_body<NL, false, true, D>(g, tile, j, s0 - s_base, lane, nullptr, nullptr, v2c, 0.0f, ev, bv, kt, nullptr, fz, &l); break;
         switch (dv) {
             LDPC_TQ_CASE(0) LDPC_TQ_CASE(1) LDPC_TQ_CASE(2) LDPC_TQ_CASE(3) LDPC_TQ_CASE(4)
             LDPC_TQ_CASE(5) LDPC_TQ_CASE(6) LDPC_TQ_CASE(7) LDPC_TQ_CASE(8)

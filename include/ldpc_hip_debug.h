@@ -34,6 +34,13 @@ int ldpc_debug_workspace_layout(const ldpc_decoder *d, int64_t batch, int64_t ou
 int ldpc_debug_resident_c2v(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop,
                             void *posterior, int32_t *iterations, void *c2v_out, void *stream);
 
+/* The variable sweep of the RCQ code-pair form turns every outgoing value v into the key
+ * [m > 0] + [m >= t1] + [m >= t2] + [m >= t3] of m = |beta * v| (thresholds4[0] is not used; device pointers, thresholds
+ * within [2^-50, 2^50]).  Runs BOTH device forms of that key on `count` arbitrary values: the float form the 4-level
+ * kernels use (clamped differences, csrc/ldpc_kernels.hip key_pair4) and the integer compare chain it replaced. */
+int ldpc_debug_key4(const float *values, int64_t count, float beta, const float thresholds4[4], uint8_t *keys_float,
+                    uint8_t *keys_compare, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -527,6 +527,53 @@ def test_rcq_code_pair_form_edge_cases(bc, B, early_stop, gpu_device, oracle_mod
         np.testing.assert_array_equal(ca, cb)                        # per-edge codes of the last executed iteration
 
 
+def test_code_pair_key_float_form_is_exact(gpu_device):
+    """The 4-level variable sweep counts thresholds with clamped float differences (key_pair4: fast VALU instructions)
+    instead of integer compares.  Both device forms against numpy on values that sit ON, one ulp below and one ulp above
+    every threshold (after the multiplication by beta), subnormals, zeros of both signs, NaN, infinities, products that
+    overflow or underflow, plus two million random bit patterns -- for thresholds at the limits the host admits to the
+    form (2^-50, 2^50), tied thresholds, and betas of both signs."""
+    import ctypes as C
+    import _native
+    lib = _native.load()
+    rng = np.random.default_rng(17)
+    f32 = np.float32
+    def neighbours(x, span=3):
+        b = np.float32(x).view(np.uint32).astype(np.int64)
+        return (b + np.arange(-span, span + 1)).clip(0, 0x7f7fffff).astype(np.uint32).view(np.float32)
+    cases = [([0.0, 0.9, 1.9, 3.1], [1.0, 0.7, -0.6, 1.3, 1e-3, 3e4]),
+             ([0.0, 2.0 ** -50, 1.0, 2.0 ** 50], [1.0, 0.5, -2.0]),
+             ([0.0, 0.37, 0.37, 5.5], [0.8, -1.0]),
+             ([0.0, 1.1754944e-38 * 2 ** 76, 2.5, 2.5], [1.0, 0.3])]
+    for thr, betas in cases:
+        thr = np.asarray(thr, f32)
+        for beta in betas:
+            beta = f32(beta)
+            special = [np.asarray([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-45, -1e-45, 1.1754944e-38, 3e-39, 3.4e38, -3.4e38,
+                                   2.0 ** -149 / 1, 2.0 ** 53, 2.0 ** 52.5, 2.0 ** -75, 2.0 ** -76], f32)]
+            for t in thr[1:]:
+                target = neighbours(t)                                  # values whose product with beta lands around t
+                with np.errstate(all="ignore"):
+                    v = (target / beta).astype(f32)
+                special += [np.concatenate([neighbours(x, 4) for x in v]), -np.concatenate([neighbours(x, 2) for x in v]), target]
+            rnd_bits = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64).astype(np.uint32).view(f32)
+            near = (thr[1 + rng.integers(0, 3, 200_000)] / beta * (1 + rng.standard_normal(200_000) * 1e-6)).astype(f32)
+            vals = np.concatenate(special + [rnd_bits, near, (rng.standard_normal(300_001) * 3).astype(f32)])
+            x = torch.from_numpy(vals).to(gpu_device)
+            t_dev = torch.from_numpy(thr).to(gpu_device)
+            kf = torch.full((len(vals),), 255, dtype=torch.uint8, device=gpu_device)
+            kc = torch.full_like(kf, 255)
+            rc = lib.ldpc_debug_key4(C.c_void_p(x.data_ptr()), len(vals), C.c_float(float(beta)), C.c_void_p(t_dev.data_ptr()),
+                                     C.c_void_p(kf.data_ptr()), C.c_void_p(kc.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            torch.cuda.synchronize()
+            with np.errstate(all="ignore"):
+                m = np.abs((beta * vals).astype(f32))                   # float32 product, as rcq_decoder.py:236-241 forms it
+                want = (m > 0).astype(np.uint8) + (m >= thr[1]) + (m >= thr[2]) + (m >= thr[3])
+            np.testing.assert_array_equal(kc.cpu().numpy(), want)
+            np.testing.assert_array_equal(kf.cpu().numpy(), want)
+
+
 def test_layered_rcq_golden_and_oracle(gpu_device, oracle_mod):
     """RCQMinSumDecoder(layered=True): the reference's own outputs (toy, 48x96), then fresh batches on the
     (1998,1512) code against the oracle in both stop modes"""
