@@ -92,6 +92,9 @@ constexpr int kResHeld = 16;         // check degrees up to this keep their valu
 #ifndef LDPC_RES_NO_PLAN_PREFETCH
 #define LDPC_RES_NO_PLAN_PREFETCH 0
 #endif
+#ifndef LDPC_RES_SELECT4
+#define LDPC_RES_SELECT4 1           // pass 2 of the check phase in hand-scheduled groups of four values (0: the compiler's form)
+#endif
 #ifndef LDPC_RES_VAR_MODE
 #define LDPC_RES_VAR_MODE 0          // 0 per-lane dispatch | 1 one scalar pass per distinct degree
 #endif
@@ -255,6 +258,33 @@ __device__ __forceinline__ unsigned group_xor(int gs, unsigned x)
     y = lane_xchg<16>(x); if (16 < gs) x ^= y;
     y = lane_xchg<32>(x); if (32 < gs) x ^= y;
     return x;
+}
+
+// Pass 2 of the check phase for TWO edges of a codeword pair (four values), hand-scheduled: out = (|x| == min1 ? o2 : o1) ^
+// sign(x).  Written in C the compiler emits compare -> s_nop -> v_cndmask per value (a lane mask needs two instructions
+// between its compare and its reader) and keeps the sign-bit constant in an SGPR -- a v_bitop3_b32 with an SGPR operand
+// issues in ~4.2 cycles instead of ~2.3 (tools/probes/valu_issue_probe.hip).  Four compares into four lane masks, four
+// selects, four bitop3 with the constant in a VGPR: no padding, 10.7 instead of ~15.5 issue cycles per value.
+__device__ __forceinline__ void res_select4(float &x0, float &x1, float &x2, float &x3, float m1a, float m1b,
+                                            uint32_t o1a, uint32_t o2a, uint32_t o1b, uint32_t o2b, uint32_t sign_v)
+{
+    unsigned long long c0, c1, c2;
+    uint32_t t0, t1, t2, t3;
+    asm("v_cmp_eq_f32_e64 %8, |%0|, %11\n\t"
+        "v_cmp_eq_f32_e64 %9, |%1|, %12\n\t"
+        "v_cmp_eq_f32_e64 %10, |%2|, %11\n\t"
+        "v_cmp_eq_f32_e64 vcc, |%3|, %12\n\t"
+        "v_cndmask_b32_e64 %4, %13, %14, %8\n\t"
+        "v_cndmask_b32_e64 %5, %15, %16, %9\n\t"
+        "v_cndmask_b32_e64 %6, %13, %14, %10\n\t"
+        "v_cndmask_b32_e32 %7, %15, %16, vcc\n\t"
+        "v_bitop3_b32 %0, %4, %0, %17 bitop3:0x78\n\t"
+        "v_bitop3_b32 %1, %5, %1, %17 bitop3:0x78\n\t"
+        "v_bitop3_b32 %2, %6, %2, %17 bitop3:0x78\n\t"
+        "v_bitop3_b32 %3, %7, %3, %17 bitop3:0x78"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+        : "v"(m1a), "v"(m1b), "v"(o1a), "v"(o2a), "v"(o1b), "v"(o2b), "v"(sign_v)
+        : "vcc");
 }
 
 // Check update of ONE degree, fully unrolled (fp32, one beta per check): the DC values are read once, stay in registers
@@ -441,8 +471,32 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
             // multiply (and the quantiser) back behind the per-edge select
             asm volatile("" : "+v"(o1[g]), "+v"(o2[g]));
         }
-#pragma unroll 4
-        for (int t = 0; t < trip; ++t) {
+        int t = 0;
+        if constexpr (G == 2 && LDPC_RES_SELECT4 != 0) {
+            uint32_t sign_v = 0x80000000u;
+            asm volatile("" : "+v"(sign_v));              // the constant in a VGPR (see res_select4)
+            for (; t + 3 < trip; t += 4) {
+                const unsigned addr = base + t * stride;
+                P va = lds_load<P>(addr), vb = lds_load<P>(addr + stride);
+                P vc = lds_load<P>(addr + 2 * stride), vd = lds_load<P>(addr + 3 * stride);
+                res_select4(va.x[0], va.x[1], vb.x[0], vb.x[1], m1[0], m1[1], o1[0], o2[0], o1[1], o2[1], sign_v);
+                lds_store<P>(addr, va);
+                lds_store<P>(addr + stride, vb);
+                res_select4(vc.x[0], vc.x[1], vd.x[0], vd.x[1], m1[0], m1[1], o1[0], o2[0], o1[1], o2[1], sign_v);
+                lds_store<P>(addr + 2 * stride, vc);
+                lds_store<P>(addr + 3 * stride, vd);
+            }
+            if (t + 1 < trip) {
+                const unsigned addr = base + t * stride;
+                P va = lds_load<P>(addr), vb = lds_load<P>(addr + stride);
+                res_select4(va.x[0], va.x[1], vb.x[0], vb.x[1], m1[0], m1[1], o1[0], o2[0], o1[1], o2[1], sign_v);
+                lds_store<P>(addr, va);
+                lds_store<P>(addr + stride, vb);
+                t += 2;
+            }
+        }
+#pragma unroll 1
+        for (; t < trip; ++t) {
             const unsigned addr = base + t * stride;
             const P v = lds_load<P>(addr);
             P o;
