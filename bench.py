@@ -239,8 +239,12 @@ SIMDS, CUS, CLOCK_HZ = 1024, 256, 2.4e9            # MI355X: 256 CUs x 4 SIMDs, 
 def issue_limits(workload, kernel, B, ms):
     """Instruction-issue and LDS-pipe time of a kernel from the SQ counters of the latest profiled build
     (profiles/counters.json, written by tools/summarize_counters.py; per-launch averages at the workload's default batch):
-      valu_issue: SQ_INSTS_VALU wave-instructions x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for 4 cycles)
-                  / 1024 SIMDs / 2.4 GHz -- the time the VALUs alone need;
+      valu_issue: SQ_INSTS_VALU wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz -- the time the VALUs alone need when every
+                  instruction costs 4 cycles.  Measured on gfx950 (tools/probes/valu_issue_probe.hip, profiles/r03_valu_issue_probe.txt):
+                  4.1-4.2 cycles for compares, selects, min/max/med3, shifts, v_perm, conversions, packed, DPP and anything with an
+                  SGPR operand; 2.2-2.4 for v_add/sub/mul/fma_f32, and/or/xor, v_add/sub_u32, v_mov, v_bitop3 on VGPR / constant
+                  operands once two waves share the SIMD -- the kernels here are mostly of the first kind, so this is an upper
+                  estimate by the share of the second kind (`cycles_per_instruction` says which figure was used);
       lds_pipe  : SQ_LDS_IDX_ACTIVE cycles (LDS array busy, bank-conflict replays included) / 256 CUs / 2.4 GHz.
     `frac` = that time / the measured launch time; the larger one is the binding limit.  None when no counters are on file
     for this batch."""
@@ -252,7 +256,8 @@ def issue_limits(workload, kernel, B, ms):
         return None
     out = {"source": ent.get("source"), "clock_GHz": CLOCK_HZ / 1e9}
     valu_ms = ent["SQ_INSTS_VALU"] * 4 / SIMDS / CLOCK_HZ * 1e3
-    out["valu_issue"] = {"wave_instructions_per_launch": ent["SQ_INSTS_VALU"], "ms": valu_ms, "frac": valu_ms / ms}
+    out["valu_issue"] = {"wave_instructions_per_launch": ent["SQ_INSTS_VALU"], "cycles_per_instruction": 4, "ms": valu_ms,
+                         "frac": valu_ms / ms}
     if "SQ_LDS_IDX_ACTIVE" in ent:
         lds_ms = ent["SQ_LDS_IDX_ACTIVE"] / CUS / CLOCK_HZ * 1e3
         out["lds_pipe"] = {"busy_cycles_per_launch": ent["SQ_LDS_IDX_ACTIVE"], "ms": lds_ms, "frac": lds_ms / ms,

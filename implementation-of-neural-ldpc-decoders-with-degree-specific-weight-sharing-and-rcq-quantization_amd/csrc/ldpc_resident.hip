@@ -95,6 +95,12 @@ constexpr int kResHeld = 16;         // check degrees up to this keep their valu
 #ifndef LDPC_RES_SELECT4
 #define LDPC_RES_SELECT4 1           // pass 2 of the check phase in hand-scheduled groups of four values (0: the compiler's form)
 #endif
+#ifndef LDPC_RES_PLAN_U32
+#define LDPC_RES_PLAN_U32 1          // plan prefetch addressed with 32-bit offsets against a scalar base (-0.3 % fp32, measured)
+#endif
+#ifndef LDPC_RES_F64_MINMAX
+#define LDPC_RES_F64_MINMAX 1        // float64 check phase: branch-free min1/min2, products hoisted, pass 2 in groups of four edges
+#endif
 #ifndef LDPC_RES_VAR_MODE
 #define LDPC_RES_VAR_MODE 0          // 0 per-lane dispatch | 1 one scalar pass per distinct degree
 #endif
@@ -287,6 +293,40 @@ __device__ __forceinline__ void res_select4(float &x0, float &x1, float &x2, flo
         : "vcc");
 }
 
+// the same for FOUR edges of one float64 codeword: compares on the 64-bit values, selects and sign on the 32-bit halves
+__device__ __forceinline__ void res_select4_f64(double (&x)[4], double m1, double o1, double o2, uint32_t sign_v)
+{
+    const unsigned long long b1 = (unsigned long long)__double_as_longlong(o1), b2 = (unsigned long long)__double_as_longlong(o2);
+    const uint32_t o1l = (uint32_t)b1, o1h = (uint32_t)(b1 >> 32), o2l = (uint32_t)b2, o2h = (uint32_t)(b2 >> 32);
+    uint32_t xh[4], rl[4], rh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[i] = (uint32_t)((unsigned long long)__double_as_longlong(x[i]) >> 32);
+    unsigned long long c0, c1, c2;
+    asm("v_cmp_eq_f64_e64 %[c0], |%[x0]|, %[m1]\n\t"
+        "v_cmp_eq_f64_e64 %[c1], |%[x1]|, %[m1]\n\t"
+        "v_cmp_eq_f64_e64 %[c2], |%[x2]|, %[m1]\n\t"
+        "v_cmp_eq_f64_e64 vcc, |%[x3]|, %[m1]\n\t"
+        "v_cndmask_b32_e64 %[l0], %[o1l], %[o2l], %[c0]\n\t"
+        "v_cndmask_b32_e64 %[h0], %[o1h], %[o2h], %[c0]\n\t"
+        "v_cndmask_b32_e64 %[l1], %[o1l], %[o2l], %[c1]\n\t"
+        "v_cndmask_b32_e64 %[h1], %[o1h], %[o2h], %[c1]\n\t"
+        "v_cndmask_b32_e64 %[l2], %[o1l], %[o2l], %[c2]\n\t"
+        "v_cndmask_b32_e64 %[h2], %[o1h], %[o2h], %[c2]\n\t"
+        "v_cndmask_b32_e32 %[l3], %[o1l], %[o2l], vcc\n\t"
+        "v_cndmask_b32_e32 %[h3], %[o1h], %[o2h], vcc\n\t"
+        "v_bitop3_b32 %[h0], %[h0], %[xh0], %[k] bitop3:0x78\n\t"
+        "v_bitop3_b32 %[h1], %[h1], %[xh1], %[k] bitop3:0x78\n\t"
+        "v_bitop3_b32 %[h2], %[h2], %[xh2], %[k] bitop3:0x78\n\t"
+        "v_bitop3_b32 %[h3], %[h3], %[xh3], %[k] bitop3:0x78"
+        : [l0] "=&v"(rl[0]), [h0] "=&v"(rh[0]), [l1] "=&v"(rl[1]), [h1] "=&v"(rh[1]), [l2] "=&v"(rl[2]), [h2] "=&v"(rh[2]),
+          [l3] "=&v"(rl[3]), [h3] "=&v"(rh[3]), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [m1] "v"(m1), [o1l] "v"(o1l), [o1h] "v"(o1h),
+          [o2l] "v"(o2l), [o2h] "v"(o2h), [xh0] "v"(xh[0]), [xh1] "v"(xh[1]), [xh2] "v"(xh[2]), [xh3] "v"(xh[3]), [k] "v"(sign_v)
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __longlong_as_double((long long)(((unsigned long long)rh[i] << 32) | rl[i]));
+}
+
 // Check update of ONE degree, fully unrolled (fp32, one beta per check): the DC values are read once, stay in registers
 // for both passes and are written back in place -- one LDS read and one LDS write per edge instead of two reads and a
 // write, no load-to-use wait in the second pass, no loop control.  Entered through a scalar switch on the wave's degree.
@@ -334,8 +374,20 @@ __device__ __forceinline__ void res_check_held(unsigned base, unsigned stride, f
         o2[g] = __float_as_uint(w2) ^ par;
         asm volatile("" : "+v"(o1[g]), "+v"(o2[g]));  // keep the two per-check values materialised (see the generic form)
     }
+    int t0 = 0;
+    if constexpr (G == 2 && LDPC_RES_SELECT4 != 0) {
+        uint32_t sign_v = 0x80000000u;
+        asm volatile("" : "+v"(sign_v));
 #pragma unroll
-    for (int t = 0; t < DC; ++t) {
+        for (int t = 0; t + 1 < DC; t += 2) {
+            res_select4(v[t].x[0], v[t].x[1], v[t + 1].x[0], v[t + 1].x[1], m1[0], m1[1], o1[0], o2[0], o1[1], o2[1], sign_v);
+            lds_store<P>(base + t * stride, v[t]);
+            lds_store<P>(base + (t + 1) * stride, v[t + 1]);
+        }
+        t0 = DC & ~1;
+    }
+#pragma unroll
+    for (int t = t0; t < DC; ++t) {
         P o;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -367,16 +419,37 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
         unsigned par[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) { m1[g] = inf_of<T>(); m2[g] = inf_of<T>(); par[g] = 0; }
-#pragma unroll 4
-        for (int t = 0; t < trip; ++t) {
-            const PD v = lds_load<PD>(base + t * stride);
+        auto absorb = [&](const PD &v) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const T a = abs_of<T>(v.x[g]);
                 par[g] ^= signbit_of<T>(v.x[g]);
+#if LDPC_RES_F64_MINMAX
+                // "if a < min1: (min2, min1) = (min1, a) elif a < min2: min2 = a" (ldpc_decoder.py:96-101) without branches:
+                // min2' = max(min(a, min2), min1), min1' = min(a, min1) -- the same values for every ordered input, and a NaN
+                // is skipped by both forms (v_min/v_max_f64 return the other operand for a quiet NaN; the initial pass
+                // quiets the caller's LLRs, arithmetic never produces a signalling one).  Three instructions instead of two
+                // compares, two exec-mask branches and five 64-bit moves.
+                T lo, m1n;
+                asm("v_min_f64 %0, |%1|, %2" : "=v"(lo) : "v"(v.x[g]), "v"(m2[g]));
+                asm("v_min_f64 %0, |%1|, %2" : "=v"(m1n) : "v"(v.x[g]), "v"(m1[g]));
+                asm("v_max_f64 %0, %1, %2" : "=v"(m2[g]) : "v"(lo), "v"(m1[g]));
+                m1[g] = m1n;
+#else
+                const T a = abs_of<T>(v.x[g]);
                 if (a < m1[g]) { m2[g] = m1[g]; m1[g] = a; }
                 else if (a < m2[g]) { m2[g] = a; }
+#endif
             }
+        };
+        {
+            int t = 0;
+            for (; t + 3 < trip; t += 4) {
+                const unsigned addr = base + t * stride;
+                const PD va = lds_load<PD>(addr), vb = lds_load<PD>(addr + stride);
+                const PD vc = lds_load<PD>(addr + 2 * stride), vd = lds_load<PD>(addr + 3 * stride);
+                absorb(va); absorb(vb); absorb(vc); absorb(vd);
+            }
+            for (; t < trip; ++t) absorb(lds_load<PD>(base + t * stride));
         }
         if constexpr (!UNI && SPLIT) {
             unsigned nzd[G];
@@ -390,9 +463,28 @@ __device__ __forceinline__ void res_check_body(const ResidentPlan &pl, unsigned 
             if (trip == 1 && gs == 1) m2[g] = m1[g];        // "min2_val = min_val" for a degree-1 check
             o1[g] = flip_sign<T>(b_check * m1[g], par[g]);
             o2[g] = flip_sign<T>(b_check * m2[g], par[g]);
+#if LDPC_RES_F64_MINMAX
+            asm volatile("" : "+v"(o1[g]), "+v"(o2[g]));   // two products per check, not one v_mul_f64 per edge (see the fp32 form)
+#endif
         }
+        int t = 0;
+#if LDPC_RES_F64_MINMAX
+        if constexpr (G == 1) {
+            uint32_t sign_v = 0x80000000u;
+            asm volatile("" : "+v"(sign_v));
+            for (; t + 3 < trip; t += 4) {
+                const unsigned addr = base + t * stride;
+                T x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = lds_load<PD>(addr + i * stride).x[0];
+                res_select4_f64(x, m1[0], o1[0], o2[0], sign_v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { PD o; o.x[0] = x[i]; lds_store<PD>(addr + i * stride, o); }
+            }
+        }
+#endif
 #pragma unroll 4
-        for (int t = 0; t < trip; ++t) {
+        for (; t < trip; ++t) {
             const unsigned addr = base + t * stride;
             const PD v = lds_load<PD>(addr);
             PD o;
@@ -745,10 +837,19 @@ __device__ __forceinline__ void res_var_phase(const ResidentPlan &pl, unsigned c
         uint2 plon, phin;
 #if !LDPC_RES_NO_PLAN_PREFETCH                        // tuning builds with more waves per SIMD trade the prefetch for registers
         {
+#if LDPC_RES_PLAN_U32
+            // 32-bit byte offsets against the scalar base (global_load ... v_off, s[base]): one shift per load instead of a
+            // sign extension and a 64-bit add each
+            const unsigned qc = (unsigned)min(qn, n - 1), qh = min(qc, (unsigned)hi_last);
+            metan = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pl.vmeta) + (size_t)(qc << 2));
+            plon = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl.vslot_lo) + (size_t)(qc << 3));
+            phin = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(pl.vslot_hi) + (size_t)(qh << 3));
+#else
             const int qc = min(qn, n - 1);
             metan = pl.vmeta[qc];
             plon = pl.vslot_lo[qc];
             phin = pl.vslot_hi[min(qc, hi_last)];
+#endif
         }
 #endif
         const int dv = (int)(meta & 0xffu);
@@ -1049,6 +1150,10 @@ __global__ __launch_bounds__(LDPC_RES_MAX_THREADS, LDPC_RES_MIN_WAVES) void resi
                     const uint4 slo = plan_unpack(plo[k]), shi = plan_unpack(phi[k]);
                     const unsigned off[8] = {slo.x, slo.y, slo.z, slo.w, shi.x, shi.y, shi.z, shi.w};
                     P l = L[q];
+                    if constexpr (!std::is_same<T, float>::value) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) l.x[g] = __builtin_canonicalize(l.x[g]);   // quiet NaNs (see the fp64 check phase)
+                    }
                     if (a.T == 0) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) l.x[g] = (T)0;

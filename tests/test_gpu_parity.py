@@ -379,6 +379,53 @@ def test_ira_batch_vs_oracle_all_decoders(early_stop, gpu_device, oracle_mod):
     assert_codes(codes_of(dec, x, early_stop), final_codes(oc, oi), 4)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_saturated_llrs_basic_and_neural2d(dtype, gpu_device, oracle_mod, engine_mode):
+    """Clipped channels hand over +-inf: |inf| takes part in min1 / min2 like any value, inf + finite = inf in the sums and
+    the posterior, a check whose other inputs are all infinite sends +-inf.  Basic (fp32 and the reference's float64) and
+    Neural-2D against the CPU restatement, every engine form (LDPC_ENGINE_MODE), both stop rules.  The inputs keep a
+    variable's infinite LLR and its infinite messages of one sign, so no inf - inf arises: a NaN is outside the path's domain
+    (the reference's sign product np.sign(nan) = nan floods the codeword; documented in DESIGN.md 4)."""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    rng = np.random.default_rng(41)
+    for name, T in (("small_96_48", 8), ("ira_1998_1512", 6)):
+        code = codes.load_code(name, T)
+        g = code.tanner_graph()
+        og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+        B = 70
+        llr = awgn(rng, B, code.n, 3.0).astype(np.float64)
+        sat = rng.random(llr.shape) < 0.02
+        llr[sat] = np.where(llr[sat] >= 0, np.inf, -np.inf)               # saturate in the direction of the sample
+        llr[0, : code.n // 3] = np.inf                                     # a third of a codeword clipped
+        for early_stop in (True, False):
+            if dtype == "f64":
+                x = torch.from_numpy(llr).to(gpu_device)
+                bits, succ, iters = BasicMinSumDecoder(code).decode(x, early_stop=early_stop)
+                ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr, 0.7, T, early_stop=early_stop, dtype=np.float64)
+            else:
+                x = torch.from_numpy(llr.astype(np.float32)).to(gpu_device)
+                bits, succ, iters = BasicMinSumDecoder(code).decode(x, early_stop=early_stop)
+                ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr.astype(np.float32), 0.7, T, early_stop=early_stop, dtype=np.float32)
+            np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+            np.testing.assert_array_equal(succ.cpu().numpy(), os_)
+            np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+            if dtype == "f32":
+                dec = Neural2DMinSumDecoder(code, weight_sharing_type=2, max_iterations=T)
+                beta, alpha = rand_weights(dec, rng)
+                with torch.no_grad():
+                    bits, post, iters = dec(x, early_stop=early_stop)
+                ob, op, oi, _ = oracle_mod.neural2d(og, llr.astype(np.float32), 2, T, beta, alpha, early_stop=early_stop)
+                np.testing.assert_array_equal(iters.cpu().numpy(), oi)
+                np.testing.assert_array_equal(bits.cpu().numpy(), ob)
+                got, want = post.cpu().numpy(), op
+                assert np.array_equal(np.isinf(got), np.isinf(want)) and not np.isnan(got).any()
+                fin = np.isfinite(want)
+                np.testing.assert_array_equal(np.sign(got[~fin]), np.sign(want[~fin]))
+                assert_post(got[fin], want[fin])
+
+
 def test_offset_minsum_vs_oracle(gpu_device, oracle_mod):
     """Neural2DOffsetMinSumDecoder (zero-aware sign product), incl. exact-zero inputs"""
     import codes
