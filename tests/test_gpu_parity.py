@@ -574,6 +574,46 @@ def test_rcq_code_pair_form_edge_cases(bc, B, early_stop, gpu_device, oracle_mod
         np.testing.assert_array_equal(ca, cb)                        # per-edge codes of the last executed iteration
 
 
+@pytest.mark.parametrize("scale", [1e-17, 3e16])
+def test_code_pair_thresholds_outside_the_float_key_range(scale, gpu_device, oracle_mod):
+    """The float form of the key (key_pair4) is admitted only for thresholds within [2^-50, 2^50]; a 4-level decoder with
+    smaller or larger thresholds keeps the integer compare chain.  Same decode, LLRs and quantisers scaled together (tiny: the
+    products are near the subnormal range; huge: beyond 2^50), code-pair form against the CPU restatement and the fp32 sweeps."""
+    import codes
+    from rcq_decoder import WeightedRCQDecoder
+    rng = np.random.default_rng(5)
+    code = codes.load_code("small_96_48", 10)
+    og = oracle_mod.OracleGraph(code.H)
+    qp = [(3.0 * scale, 1.3), (5.0 * scale, 1.3), (7.0 * scale, 1.3)]
+    B, T = 300, 6
+    llr = ((rng.standard_normal((B, code.n)) * 2.5 + 1.0) * scale).astype(np.float32)
+    llr[0, ::4] = 0.0
+    x = torch.from_numpy(llr).to(gpu_device)
+    dec = WeightedRCQDecoder(code, 3, 8, qp, weight_sharing_type=2, max_iterations=T)
+    with torch.no_grad():
+        for i, p_ in enumerate(dec.beta_weights.values()):
+            p_.fill_(float(np.float32([0.8, -0.6, 1.3][i % 3])))
+        for p_ in dec.alpha_weights.values():
+            p_.fill_(float(np.float32(rng.uniform(0.7, 1.2))))
+    beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
+    alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
+    eng = dec._get_engine(gpu_device)
+    for early_stop in (False, True):
+        eng.set_mode("pair")
+        assert eng.info()["stream_form"] == "rcq-code-pair"
+        a = eng.decode(x, early_stop=early_stop)
+        ca = eng.debug_c2v(B).cpu().numpy()
+        eng.set_mode("sweeps")
+        b = eng.decode(x, early_stop=early_stop)
+        cb = eng.debug_c2v(B).cpu().numpy()
+        ob, op, oi, osucc = oracle_mod.weighted_rcq(og, llr, 3, qp, 2, T, beta, alpha, early_stop=early_stop)
+        np.testing.assert_array_equal(a.bits.cpu().numpy(), ob)
+        np.testing.assert_array_equal(a.iterations.cpu().numpy(), oi)
+        np.testing.assert_array_equal(a.posterior.cpu().numpy(), op)
+        assert torch.equal(a.posterior, b.posterior) and torch.equal(a.bits, b.bits)
+        np.testing.assert_array_equal(ca, cb)
+
+
 def test_code_pair_key_float_form_is_exact(gpu_device):
     """The 4-level variable sweep counts thresholds with clamped float differences (key_pair4: fast VALU instructions)
     instead of integer compares.  Both device forms against numpy on values that sit ON, one ulp below and one ulp above
