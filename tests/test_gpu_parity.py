@@ -1069,13 +1069,31 @@ def test_weight_update_is_picked_up(gpu_device, oracle_mod):
     dec = Neural2DMinSumDecoder(code, 2, 6)
     llr = awgn(rng, 70, 96, 2.5)
     x = torch.from_numpy(llr).to(gpu_device)
-    for _ in range(2):
-        beta, alpha = rand_weights(dec, rng)
+    def check(beta, alpha):
         bits, post, iters = dec(x)
         ob, op, oi, _ = oracle_mod.neural2d(og, llr, 2, 6, beta, alpha)
         np.testing.assert_array_equal(bits.detach().cpu().numpy(), ob)
         np.testing.assert_array_equal(iters.detach().cpu().numpy(), oi)
         assert_post(post.detach().cpu().numpy(), op)
+    for _ in range(2):
+        check(*rand_weights(dec, rng))                                # in-place fill_ (version counter)
+    # the tables are re-flattened only when the parameter fingerprint changes (version counters, identities, storage):
+    # every way of changing a weight must show in it
+    as_dicts = lambda: ({k: float(v.item()) for k, v in dec.beta_weights.items()}, {k: float(v.item()) for k, v in dec.alpha_weights.items()})
+    k0 = sorted(dec.beta_weights.keys())[0]
+    dec.beta_weights[k0].data = torch.tensor([0.5625])                # storage replaced
+    check(*as_dicts())
+    dec.beta_weights[k0] = torch.nn.Parameter(torch.tensor([0.8125]))  # Parameter replaced under the key
+    check(*as_dicts())
+    sd = {k: torch.full_like(v, 0.6875) for k, v in dec.state_dict().items()}
+    dec.load_state_dict(sd)                                           # the reference's checkpoint path
+    check(*as_dicts())
+    with torch.no_grad():
+        dec.alpha_weights[sorted(dec.alpha_weights.keys())[-1]].mul_(1.25)   # optimizer-style in-place update
+    check(*as_dicts())
+    stamp = dec._stamp
+    check(*as_dicts())                                                # nothing changed: same fingerprint, same results
+    assert dec._stamp == stamp
 
 
 def test_packed_bits_and_threads(gpu_device):
