@@ -149,6 +149,8 @@ struct Workspace {
     char *c2v_prev = nullptr;        // saving forward only: previous iteration's c2v slice (latched rows are carried over)
     uint64_t *bitsT = nullptr, *done = nullptr;
     int *iters = nullptr;
+    unsigned long long *unsat = nullptr;     // [tiles][vec] partial syndrome words and
+    int *ticket = nullptr;                   // [tiles] block tickets of syndrome_latch_chunks (both zero between launches)
     size_t total = 0;
 };
 
@@ -174,16 +176,32 @@ Workspace carve(const ldpc_decoder *d, int64_t batch, void *base)
     const size_t o_bits = take((size_t)w.tiles * n * w.vec * sizeof(uint64_t));
     const size_t o_done = take((size_t)w.tiles * w.vec * sizeof(uint64_t));
     const size_t o_it = take(tw * sizeof(int));
+    const size_t o_unsat = take((size_t)w.tiles * w.vec * sizeof(uint64_t));
+    const size_t o_ticket = take((size_t)w.tiles * sizeof(int));
     w.total = off;
     if (base) {
         char *b = (char *)base;
         w.llrT = b + o_llr; w.v2c = b + o_v2c; w.c2v = b + o_c2v; w.postT = b + o_post;
         w.bitsT = (uint64_t *)(b + o_bits); w.done = (uint64_t *)(b + o_done); w.iters = (int *)(b + o_it);
+        w.unsat = (unsigned long long *)(b + o_unsat); w.ticket = (int *)(b + o_ticket);
     }
     return w;
 }
 
 // ---- launch helpers, one per kernel family ------------------------------------------------
+// syndrome + latch: one block per tile when the tiles fill the chip, else `chunks` blocks per tile (syndrome_latch_chunks)
+template <int VEC>
+void launch_syndrome(const GraphDev &g, const Workspace &w, int it_plus_1, int latch, hipStream_t s)
+{
+    const int max_chunks = (g.m + kBlock - 1) / kBlock;
+    const int chunks = std::min(max_chunks, std::max(1, 1024 / std::max(w.tiles, 1)));
+    if (chunks <= 1)
+        hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done, w.iters, it_plus_1, latch);
+    else
+        hipLaunchKernelGGL((syndrome_latch_chunks<VEC>), dim3((unsigned)w.tiles * chunks), dim3(kBlock), 0, s, g, w.bitsT, w.done,
+                           w.iters, it_plus_1, latch, chunks, w.unsat, w.ticket);
+}
+
 template <typename T, int VEC>
 int launch_cn(const ldpc_decoder *d, const Workspace &w, int it, bool use_done, hipStream_t s)
 {
@@ -577,7 +595,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     {
         const long long cnt = (long long)w.tiles * W;
         hipLaunchKernelGGL((init_state<VEC>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, w.done,
-                           w.iters, (long long)batch, w.tiles, T_it);
+                           w.iters, (long long)batch, w.tiles, T_it, w.unsat, w.ticket);
     }
     HIP_TRY(hipGetLastError());
 
@@ -643,8 +661,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                                     : launch_vn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
                 if (early_stop)
-                    hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
-                                       w.iters, it + 1, 1);
+                    launch_syndrome<VEC>(g, w, it + 1, 1, s);
             }
         }
     } else if (use_gather(d) && !saved) {
@@ -670,8 +687,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                     if (rc) return rc;
                 }
                 if (early_stop)
-                    hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
-                                       w.iters, it + 1, 1);
+                    launch_syndrome<VEC>(g, w, it + 1, 1, s);
             }
         }
     } else
@@ -694,13 +710,11 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s, /*store_posterior=*/true, rows);
         if (rc) return rc;
         if (early_stop) {
-            hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
-                               w.iters, it + 1, 1);
+            launch_syndrome<VEC>(g, w, it + 1, 1, s);
         }
     }
     if (!early_stop) {
-        hipLaunchKernelGGL((syndrome_latch<VEC>), dim3(w.tiles), dim3(kBlock), 0, s, g, w.bitsT, w.done,
-                           w.iters, T_it, 0);
+        launch_syndrome<VEC>(g, w, T_it, 0, s);
     } else if (T_it == 0) {
         // reference: the loop never ran, success False, iterations 0 -> clear the (padding) latch bits
         HIP_TRY(hipMemsetAsync(w.done, 0, (size_t)w.tiles * VEC * sizeof(uint64_t), s));

@@ -2138,6 +2138,77 @@ __global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint6
     }
 }
 
+// The same for FEW tiles (small batches of a code that does not fit LDS: the reference's one-codeword call on the (16200,7200)
+// code ran one 256-thread block over all 9000 checks, ~60 us per iteration): `chunks` blocks per tile, each over every
+// chunks-th group of 256 checks; partial words are OR-ed into unsat_g[tile][VEC], and the block that draws the last ticket of its
+// tile applies the latch and leaves unsat_g / ticket zeroed for the next launch.  No block can read `done` after the latch of
+// its own launch: the latch needs every block's ticket, and a tile whose codewords are all done draws none at all.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void syndrome_latch_chunks(GraphDev g, const uint64_t *__restrict__ bitsT,
+                                                                uint64_t *__restrict__ done, int *__restrict__ iters,
+                                                                int it_plus_1, int latch, int chunks,
+                                                                unsigned long long *__restrict__ unsat_g, int *__restrict__ ticket)
+{
+    constexpr int W = kWave * VEC;
+    __shared__ unsigned long long unsat[VEC];
+    __shared__ int is_last;
+    const int tile = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    if (threadIdx.x < VEC) unsat[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (latch) {
+        bool all = true;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) all = all && (done[(size_t)tile * VEC + c] == ~0ull);
+        if (all) return;
+    }
+    uint64_t acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0;
+    const uint64_t *b = bitsT + (size_t)tile * g.n * VEC;
+    for (int i = chunk * kBlock + threadIdx.x; i < g.m; i += chunks * kBlock) {
+        uint64_t x[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c] = 0;
+        const int e1 = g.check_ptr[i + 1];
+        for (int e = g.check_ptr[i]; e < e1; ++e) {
+            const uint64_t *w = b + (size_t)g.var_idx[e] * VEC;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) x[c] ^= w[c];
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] |= x[c];
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c)
+        if (acc[c]) atomicOr(&unsat[c], (unsigned long long)acc[c]);
+    __syncthreads();
+    if ((int)threadIdx.x < VEC && unsat[threadIdx.x]) atomicOr(&unsat_g[(size_t)tile * VEC + threadIdx.x], unsat[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&ticket[tile], 1) == chunks - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if ((int)threadIdx.x < VEC) unsat[threadIdx.x] = atomicOr(&unsat_g[(size_t)tile * VEC + threadIdx.x], 0ull);   // the tile's OR, read at L2
+    __syncthreads();
+    if ((int)threadIdx.x < W) {
+        const int w = threadIdx.x, c = w % VEC, l = w / VEC;
+        const uint64_t sat = ~(uint64_t)unsat[c];
+        if (latch) {
+            const uint64_t was = done[(size_t)tile * VEC + c];
+            if (((sat & ~was) >> l) & 1ull) iters[(size_t)tile * W + w] = it_plus_1;
+        }
+    }
+    __syncthreads();   // all reads of `done` above precede the update below
+    if ((int)threadIdx.x < VEC) {
+        const int c = threadIdx.x;
+        const uint64_t sat = ~(uint64_t)unsat[c];
+        done[(size_t)tile * VEC + c] = latch ? (done[(size_t)tile * VEC + c] | sat) : sat;
+        unsat_g[(size_t)tile * VEC + c] = 0ull;
+    }
+    if (threadIdx.x == 0) ticket[tile] = 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Reference-compatible "layered" RCQ schedule (RCQMinSumDecoder._decode_layered,
 // rcq_decoder.py:281-350).  As written there the per-check message matrix is re-created for every
@@ -2362,12 +2433,14 @@ __global__ __launch_bounds__(kWave) void layered_rcq(GraphDev g, float *__restri
 // done masks: padding codewords (>= batch) start frozen; iterations start at T
 template <int VEC>
 __global__ void init_state(uint64_t *__restrict__ done, int *__restrict__ iters, long long batch,
-                           int tiles, int T)
+                           int tiles, int T, unsigned long long *__restrict__ unsat_g, int *__restrict__ ticket)
 {
     constexpr int W = kWave * VEC;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < (long long)tiles * W) iters[gid] = T;
+    if (gid < tiles) ticket[gid] = 0;
     if (gid < (long long)tiles * VEC) {
+        unsat_g[gid] = 0ull;
         const int tile = (int)(gid / VEC), c = (int)(gid % VEC);
         uint64_t mask = 0;
         for (int l = 0; l < kWave; ++l) {
