@@ -2085,6 +2085,25 @@ __global__ __launch_bounds__(kBlock, LDPC_GATHER_WAVES) void cn_gather(GraphDev 
 //   latch = true : done |= (syndrome == 0); iterations = it+1 for newly done codewords
 //   latch = false: fixed-T mode, done := (syndrome == 0)   (reported as `success`)
 // ------------------------------------------------------------------------------------------
+// XOR of the decision words of check i's variables.  Groups of four edges: the four variable indices are requested together, then
+// the four word rows -- two load round trips per group instead of eight dependent ones (the kernel is bound by that chain).
+template <int VEC>
+__device__ __forceinline__ void syndrome_row(const GraphDev &g, const uint64_t *__restrict__ b, int i, uint64_t (&x)[VEC])
+{
+    const int e1 = g.check_ptr[i + 1];
+    for (int e = g.check_ptr[i]; e < e1; e += 4) {
+        const int last = e1 - 1, cnt = e1 - e;                       // a short last group re-reads its last edge and masks it out
+        const int v0 = g.var_idx[e], v1 = g.var_idx[min(e + 1, last)], v2 = g.var_idx[min(e + 2, last)], v3 = g.var_idx[min(e + 3, last)];
+        const uint64_t *w0 = b + (size_t)v0 * VEC, *w1 = b + (size_t)v1 * VEC, *w2 = b + (size_t)v2 * VEC, *w3 = b + (size_t)v3 * VEC;
+        uint64_t t0[VEC], t1[VEC], t2[VEC], t3[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { t0[c] = w0[c]; t1[c] = w1[c]; t2[c] = w2[c]; t3[c] = w3[c]; }
+        const uint64_t k1 = cnt > 1 ? ~0ull : 0ull, k2 = cnt > 2 ? ~0ull : 0ull, k3 = cnt > 3 ? ~0ull : 0ull;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c] ^= (t0[c] ^ (t1[c] & k1)) ^ ((t2[c] & k2) ^ (t3[c] & k3));
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint64_t *__restrict__ bitsT,
                                                          uint64_t *__restrict__ done,
@@ -2109,12 +2128,7 @@ __global__ __launch_bounds__(kBlock) void syndrome_latch(GraphDev g, const uint6
         uint64_t x[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) x[c] = 0;
-        const int e1 = g.check_ptr[i + 1];
-        for (int e = g.check_ptr[i]; e < e1; ++e) {
-            const uint64_t *w = b + (size_t)g.var_idx[e] * VEC;
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) x[c] ^= w[c];
-        }
+        syndrome_row<VEC>(g, b, i, x);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc[c] |= x[c];
     }
@@ -2169,12 +2183,7 @@ __global__ __launch_bounds__(kBlock) void syndrome_latch_chunks(GraphDev g, cons
         uint64_t x[VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) x[c] = 0;
-        const int e1 = g.check_ptr[i + 1];
-        for (int e = g.check_ptr[i]; e < e1; ++e) {
-            const uint64_t *w = b + (size_t)g.var_idx[e] * VEC;
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) x[c] ^= w[c];
-        }
+        syndrome_row<VEC>(g, b, i, x);
 #pragma unroll
         for (int c = 0; c < VEC; ++c) acc[c] |= x[c];
     }
