@@ -304,6 +304,44 @@ def test_product_never_imports_the_oracle():
         assert "oracle" not in open(os.path.join(PKG, "csrc", fn)).read().lower(), fn
 
 
+def test_parameter_fingerprint_sees_every_kind_of_weight_change():
+    """The degree-shared decoders re-flatten their ParameterDicts only when `_param_stamp()` changes: in-place updates (version
+    counters), replaced storage, a replaced Parameter, load_state_dict and a changed iteration count must all show; reading must not."""
+    import codes
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import WeightedRCQDecoder
+    code = codes.load_code("small_96_48", 5)
+    for dec in (Neural2DMinSumDecoder(code, 2, 5), WeightedRCQDecoder(code, 3, 8, QP, weight_sharing_type=3, max_iterations=5)):
+        seen = {dec._param_stamp()}
+        def changed():
+            st = dec._param_stamp()
+            new = st not in seen
+            seen.add(st)
+            return new
+        assert not changed()                                              # reading twice: same stamp
+        _ = dec.weight_tables()
+        _ = [float(p.item()) for p in dec.beta_weights.values()]
+        assert not changed()
+        k = sorted(dec.beta_weights.keys())[0]
+        with torch.no_grad():
+            dec.beta_weights[k].fill_(0.5)
+        assert changed()
+        with torch.no_grad():
+            list(dec.parameters())[-1].mul_(1.5)                          # an alpha where the sharing type has any
+        assert changed()
+        dec.beta_weights[k].data = torch.tensor([0.25])
+        assert changed()
+        dec.beta_weights[k] = torch.nn.Parameter(torch.tensor([0.75]))
+        assert changed()
+        dec.load_state_dict({n: torch.full_like(v, 0.625) for n, v in dec.state_dict().items()})
+        assert changed()
+        opt = torch.optim.SGD(dec.parameters(), lr=0.1)
+        for p_ in dec.parameters():
+            p_.grad = torch.ones_like(p_)
+        opt.step()
+        assert changed()
+
+
 def test_decoder_objects_pickle_without_native_handles():
     import copy
     import codes
