@@ -117,7 +117,7 @@ class DecoderDesc(C.Structure):
 PRODUCT_EXPORTS = ("ldpc_graph_create", "ldpc_graph_destroy", "ldpc_graph_info", "ldpc_decoder_create",
                    "ldpc_decoder_set_mode", "ldpc_decoder_info",
                    "ldpc_decoder_set_weights", "ldpc_decoder_destroy", "ldpc_decoder_workspace_bytes",
-                   "ldpc_decode", "ldpc_last_error", "ldpc_abi_version", "ldpc_source_hash",
+                   "ldpc_decode", "ldpc_decode_capped", "ldpc_last_error", "ldpc_abi_version", "ldpc_source_hash",
                    "ldpc_train_saved_bytes", "ldpc_train_workspace_bytes", "ldpc_decode_saving", "ldpc_backward")
 # ... and the measurement / test hooks of include/ldpc_hip_debug.h (bench.py's per-kernel timing, the tests' state dumps)
 DEBUG_EXPORTS = ("ldpc_debug_sweep", "ldpc_debug_workspace_layout", "ldpc_debug_resident_c2v", "ldpc_debug_key4")
@@ -168,6 +168,8 @@ def load():
         lib.ldpc_decoder_workspace_bytes.argtypes = [vp, i64]
         lib.ldpc_decode.restype = C.c_int
         lib.ldpc_decode.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.ldpc_decode_capped.restype = C.c_int
+        lib.ldpc_decode_capped.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         lib.ldpc_debug_sweep.restype = C.c_int
         lib.ldpc_debug_sweep.argtypes = [vp, i64, i32, i32, vp, C.c_size_t, vp]
         lib.ldpc_debug_workspace_layout.restype = C.c_int

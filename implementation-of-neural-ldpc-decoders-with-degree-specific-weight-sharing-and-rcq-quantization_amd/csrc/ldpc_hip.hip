@@ -9,6 +9,7 @@
 #include "ldpc_layered.hip"
 
 #include <algorithm>
+#include <climits>
 #include <mutex>
 #include <set>
 #include <cmath>
@@ -142,6 +143,11 @@ int pick_vec(const ldpc_decoder *d, int64_t batch)
     if (d->schedule != LDPC_SCHED_FLOODING) return 1;      // layered: one dependent chain per wave, as many waves as possible
     return d->dtype == LDPC_F64 ? 2 : 4;
 }
+
+// ldpc_decode_capped: the calling thread's decode runs at most this many iterations (INT_MAX outside such a call).  The decode
+// entry points only enqueue work, so the cap lives exactly as long as the call that set it.
+thread_local int tl_iter_cap = INT_MAX;
+inline int capped_T(const ldpc_decoder *d) { return std::min(d->T, tl_iter_cap); }
 
 struct Workspace {
     int vec = 0, tiles = 0;
@@ -535,7 +541,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     constexpr int W = 64 * VEC;
     constexpr int JT = transpose_vars<T>();
     const GraphDev g = d->g->dev();
-    const int T_it = d->T;
+    const int T_it = capped_T(d);
     const int vc = (g.n + JT - 1) / JT;
     const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc));       // transposes: one block per (tile, 64-codeword run, chunk)
 
@@ -1104,7 +1110,7 @@ int decode_resident(const ldpc_decoder *d, const void *llr, int64_t batch, int32
 {
     DeviceGuard guard(d->g->device);
     ResidentArgs a{};
-    a.llr = (const float *)llr; a.batch = batch; a.T = d->T; a.early_stop = early_stop != 0;
+    a.llr = (const float *)llr; a.batch = batch; a.T = capped_T(d); a.early_stop = early_stop != 0;
     a.beta = (const float *)d->beta; a.n_beta = d->n_beta;
     a.alpha = (const float *)d->alpha; a.n_alpha = d->n_alpha;
     a.oms_alpha = (const float *)d->oms_alpha; a.n_oms_alpha = d->n_oms_alpha;
@@ -1212,7 +1218,7 @@ int decode_layered_lds(const ldpc_decoder *d, const void *llr, int64_t batch, in
         auto kfn = pl.row_shift ? layered_lds<LW_, NL_, ES_, D1_, Z0_, SO_, true> : layered_lds<LW_, NL_, ES_, D1_, Z0_, SO_, false>; \
         if (int rc_ = allow_full_lds((const void *)kfn, d->g->device)) return rc_;                                   \
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kWave), d->lay_lds, s, pl, (const float *)llr, (long long)batch, \
-                           (const float *)d->thresholds, d->n_levels, (const int *)d->q_of_iter_dev, d->T,           \
+                           (const float *)d->thresholds, d->n_levels, (const int *)d->q_of_iter_dev, capped_T(d),   \
                            bits, (float *)posterior, iterations, success, packed_bits);                             \
     } while (0)
     // the common case (bc = 3, no degree-1 check, zero reconstructs to zero) gets the lean instantiation per stop mode;
@@ -1599,6 +1605,19 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
     if (d->dtype == LDPC_F64)
         return decode_dispatch<double>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
     return decode_dispatch<float>(d, llr, batch, early_stop != 0, bits, posterior, iterations, success, packed_bits, w, s);
+}
+
+int ldpc_decode_capped(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop, int32_t max_iterations,
+                       int32_t *bits, void *posterior, int32_t *iterations, uint8_t *success, uint8_t *packed_bits,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (max_iterations < 1) return fail(LDPC_ERR_ARG, "max_iterations must be >= 1");
+    struct Cap {
+        explicit Cap(int c) { tl_iter_cap = c; }
+        ~Cap() { tl_iter_cap = INT_MAX; }
+    } cap(max_iterations);
+    return ldpc_decode(d, llr, batch, early_stop, bits, posterior, iterations, success, packed_bits, workspace, workspace_bytes,
+                       stream);
 }
 
 }  // extern "C"

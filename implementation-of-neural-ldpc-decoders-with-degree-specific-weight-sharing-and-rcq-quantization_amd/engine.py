@@ -244,8 +244,9 @@ class DecodeEngine:
             return ws
 
     def decode(self, llr: torch.Tensor, *, early_stop: bool = True, want_bits: bool = True,
-               want_posterior: bool = True, want_packed: bool = False) -> DecodeResult:
-        """llr: [B, n] tensor on this engine's GPU, dtype == engine dtype."""
+               want_posterior: bool = True, want_packed: bool = False, max_iters: Optional[int] = None) -> DecodeResult:
+        """llr: [B, n] tensor on this engine's GPU, dtype == engine dtype.  max_iters: run at most that many of the decoder's
+        iterations (ldpc_decode_capped; a codeword open at the cap reports iterations = cap, success = False)."""
         if llr.device != self.device:
             raise ValueError(f"llr is on {llr.device}, engine on {self.device}")
         if llr.dtype != self.dtype:
@@ -265,9 +266,14 @@ class DecodeEngine:
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-                nat.check(self._lib.ldpc_decode(self.handle, p(llr), B, int(bool(early_stop)), p(bits), p(post),
-                                                p(iters), p(succ), p(packed), p(ws), ws.numel(),
-                                                C.c_void_p(stream)), "ldpc_decode")
+                if max_iters is None:
+                    nat.check(self._lib.ldpc_decode(self.handle, p(llr), B, int(bool(early_stop)), p(bits), p(post),
+                                                    p(iters), p(succ), p(packed), p(ws), ws.numel(),
+                                                    C.c_void_p(stream)), "ldpc_decode")
+                else:
+                    nat.check(self._lib.ldpc_decode_capped(self.handle, p(llr), B, int(bool(early_stop)), int(max_iters),
+                                                           p(bits), p(post), p(iters), p(succ), p(packed), p(ws),
+                                                           ws.numel(), C.c_void_p(stream)), "ldpc_decode_capped")
         return DecodeResult(bits, post, iters, succ.bool(), packed)
 
     # ------------------------------------------------------------------ small host batches (the reference's call shape)

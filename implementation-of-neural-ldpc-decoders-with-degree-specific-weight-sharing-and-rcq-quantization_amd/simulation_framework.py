@@ -58,6 +58,8 @@ class SimulationConfig:
     batch_frames: int = 8192
     seed: int = 0
     llr_convention: str = "decoder"
+    staged_early_stop: bool = True          # streaming engine: cap the block's first stage, finish stragglers as a small batch
+    stage_min_block: int = 1024             # ... only for blocks of at least this many frames
 
 
 class SimulationResult:
@@ -113,6 +115,45 @@ def _engine_of(decoder, device):
     raise TypeError(f"{type(decoder).__name__} is not one of this package's decoders")
 
 
+def _decode_block(eng, llr: torch.Tensor, cap):
+    """Early-stop decode of one block -> (bits, iterations), exactly what eng.decode(llr, early_stop=True) returns.
+    The streaming engine freezes whole 256-codeword tiles only, so a block whose codewords stop after 6 iterations on average
+    but has a straggler in every tile costs all T iterations.  With `cap` (chosen by _next_cap from the previous block) the
+    block runs in two stages: every codeword up to `cap` iterations (ldpc_decode_capped: the decoder's own per-iteration tables),
+    then the few still open ones again from their LLRs as a small batch with the full iteration count.  A codeword's decode does
+    not depend on its neighbours in the batch, and a codeword that stops within the cap stops at the same iteration with the
+    same decisions either way: the result is identical to the one-stage decode."""
+    if cap is None:
+        res = eng.decode(llr, early_stop=True, want_posterior=False)
+        return res.bits, res.iterations
+    res = eng.decode(llr, early_stop=True, want_posterior=False, max_iters=int(cap))
+    bits, iters = res.bits, res.iterations
+    open_idx = torch.nonzero(~res.success, as_tuple=False).reshape(-1)
+    if open_idx.numel():
+        rest = eng.decode(llr.index_select(0, open_idx).contiguous(), early_stop=True, want_posterior=False)
+        bits.index_copy_(0, open_idx, rest.bits)
+        iters.index_copy_(0, open_idx, rest.iterations)
+    return bits, iters
+
+
+def _next_cap(eng, iters: torch.Tensor, min_block: int = 1024):
+    """Iteration cap for the next block from this block's stop iterations: the cap c minimising c + open(c) * (T + 2), the cost
+    in full-block iterations of stage one plus the restart of the codewords still open after c (open(c) = share with more than c
+    iterations; one that never converges counts as open for every c < T).  None when the engine stops codeword by codeword
+    anyway (LDS-resident) or when staging would not save a quarter of the block's work."""
+    info = eng.info()
+    T = int(eng.iters)
+    if info["engine"] != "stream" or T < 4 or iters.numel() < min_block:
+        return None
+    hist = torch.bincount(iters.to(torch.int64).clamp_(0, T), minlength=T + 1).to(torch.float64)
+    open_after = 1.0 - torch.cumsum(hist, 0) / float(iters.numel())            # open_after[c] = share with iterations > c
+    c = torch.arange(T + 1, dtype=torch.float64, device=open_after.device)
+    cost = c + open_after * (T + 2.0)
+    cost[0] = float("inf")
+    best = int(torch.argmin(cost[:T]).item()) if T > 1 else T
+    return best if float(cost[best]) <= 0.75 * T else None
+
+
 class LDPSimulator:
     """LDPC decoder simulator on the batched GPU engine"""
 
@@ -142,16 +183,18 @@ class LDPSimulator:
         gen.manual_seed(int(self.config.seed) * 1_000_003 + int(round(snr_db * 1000)))
         frame_errors = bit_errors = total_iterations = total_frames = 0
         block = max(1, int(self.config.batch_frames))
+        cap = None                                                              # iteration cap of the next block's first stage
         while total_frames < max_frames and frame_errors < max_errors:
             frames = min(block, max_frames - total_frames)
             llr = self._draw_llr(gen, frames, code.n, float(snr_db), device)
-            res = eng.decode(llr, early_stop=True, want_posterior=False)
-            wrong = res.bits != 0                                               # all-zero codeword was sent
+            bits, iters = _decode_block(eng, llr, cap)
+            cap = _next_cap(eng, iters, int(self.config.stage_min_block)) if self.config.staged_early_stop else None
+            wrong = bits != 0                                                   # all-zero codeword was sent
             ferr = wrong.any(dim=1)
             take = frames_to_count(ferr.cpu().numpy(), total_frames, frame_errors, max_frames, max_errors)
             frame_errors += int(ferr[:take].sum().item())
             bit_errors += int(wrong[:take].sum().item())
-            total_iterations += int(res.iterations[:take].sum().item())
+            total_iterations += int(iters[:take].sum().item())
             total_frames += take
         fer = frame_errors / total_frames if total_frames > 0 else 0.0
         ber = bit_errors / (total_frames * code.n) if total_frames > 0 else 0.0

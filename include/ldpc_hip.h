@@ -156,6 +156,16 @@ int ldpc_decode(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t e
                 int32_t *bits, void *posterior, int32_t *iterations, uint8_t *success,
                 uint8_t *packed_bits, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ldpc_decode with at most `max_iterations` (>= 1) of the decoder's iterations: iteration t still uses the decoder's own
+ * tables of iteration t (weights, quantiser schedule), a codeword open at the cap reports iterations = cap, success = 0.
+ * No reference counterpart: it lets a batched caller with early stop (the Monte-Carlo driver, simulation_framework.py:85-139
+ * of the reference run block-wise) decode a block up to the iteration by which most codewords have stopped and finish the few
+ * stragglers as a small second batch -- the streaming engine freezes whole 256-codeword tiles only. */
+int ldpc_decode_capped(const ldpc_decoder *d, const void *llr, int64_t batch, int32_t early_stop,
+                       int32_t max_iterations, int32_t *bits, void *posterior, int32_t *iterations,
+                       uint8_t *success, uint8_t *packed_bits, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* ---- gradient (training) path -------------------------------------------------------------
  * Replaces torch autograd through Neural2DMinSumDecoder.forward / NeuralMinSumDecoder.forward
  * (neural_2d_decoder.py:133-225 under loss.backward(), training_framework.py:127-134): the

@@ -1120,6 +1120,57 @@ def test_packed_bits_and_threads(gpu_device):
         np.testing.assert_array_equal(o, ref_bits.detach().cpu().numpy())
 
 
+@pytest.mark.parametrize("early_stop", [True, False])
+def test_capped_decode(early_stop, gpu_device, oracle_mod, engine_mode):
+    """ldpc_decode_capped: at most c of the decoder's iterations, iteration t with the decoder's own tables of iteration t.
+    Basic (no per-iteration tables) equals the CPU restatement run with T = c; for every decoder a codeword that stops within
+    the cap has the full decode's outputs, one still open reports iterations = c, success = False, and the posterior after c
+    iterations (fixed T: equal to the first c iterations of the full schedule, checked through Basic).  Every engine form."""
+    import codes
+    from ldpc_decoder import BasicMinSumDecoder
+    from neural_2d_decoder import Neural2DMinSumDecoder
+    from rcq_decoder import RCQMinSumDecoder
+    rng = np.random.default_rng(12)
+    code = codes.load_code("small_96_48", 10)
+    g = code.tanner_graph()
+    og = oracle_mod.OracleGraph(n=g.n, check_ptr=g.check_ptr, var_idx=g.var_idx)
+    llr = awgn(rng, 300, code.n, 3.0)
+    x = torch.from_numpy(llr).to(gpu_device)
+    n2d = Neural2DMinSumDecoder(code, 2, 10)
+    rand_weights(n2d, rng)
+    engines = {"basic": BasicMinSumDecoder(code, 0.7)._engine(torch.float32, gpu_device),
+               "rcq": RCQMinSumDecoder(code, 3, 8, QP, 10)._get_engine(gpu_device) if hasattr(RCQMinSumDecoder, "_get_engine") else None,
+               "neural2d": n2d._get_engine(gpu_device)}
+    if engines["rcq"] is None:
+        dec = RCQMinSumDecoder(code, 3, 8, QP, 10)
+        dec.decode(x[:2])
+        engines["rcq"] = dec._engine
+    for name, eng in engines.items():
+        full = eng.decode(x, early_stop=early_stop)
+        for c in (1, 3, 10, 25):
+            part = eng.decode(x, early_stop=early_stop, max_iters=c)
+            if c >= 10:                                               # a cap at or above T changes nothing
+                assert torch.equal(part.bits, full.bits) and torch.equal(part.iterations, full.iterations)
+                assert torch.equal(part.success, full.success) and torch.equal(part.posterior, full.posterior)
+                continue
+            if early_stop:
+                inside = full.success & (full.iterations <= c)
+                assert torch.equal(part.success, inside)
+                assert torch.equal(part.bits[inside], full.bits[inside]) and torch.equal(part.posterior[inside], full.posterior[inside])
+                assert torch.equal(part.iterations[inside], full.iterations[inside])
+                assert bool((part.iterations[~inside] == c).all())
+            else:
+                assert bool((part.iterations == c).all())
+            if name == "basic":
+                ob, op, oi, os_ = oracle_mod.basic_minsum(og, llr, 0.7, c, early_stop=early_stop, dtype=np.float32)
+                np.testing.assert_array_equal(part.bits.cpu().numpy(), ob)
+                np.testing.assert_array_equal(part.iterations.cpu().numpy(), oi)
+                np.testing.assert_array_equal(part.success.cpu().numpy(), os_)
+                assert_post(part.posterior.cpu().numpy(), op)
+    with pytest.raises(Exception):
+        engines["basic"].decode(x, max_iters=0)
+
+
 def test_decode_is_capturable_in_a_hip_graph(gpu_device, engine_mode):
     """ldpc_decode only enqueues work on the caller's stream (no allocation, no synchronisation), so a launch-bound
     caller can capture it once and replay it: replays on new inputs equal eager decodes"""

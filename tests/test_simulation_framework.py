@@ -111,8 +111,9 @@ def test_simulator_counters_match_direct_decode(gpu_device, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("staged", [False, True])
 @pytest.mark.parametrize("family", ["basic", "rcq", "neural2d"])
-def test_simulator_counters_match_oracle_decoded_blocks(family, gpu_device, oracle_mod, tmp_path):
+def test_simulator_counters_match_oracle_decoded_blocks(family, staged, gpu_device, oracle_mod, tmp_path):
     """SURVEY 8f-1 against the ORACLE: the blocks the simulator draws are decoded frame by frame on the CPU by the
     restatement of the reference's decoders, the reference's own per-frame loop (simulation_framework.py:110-132: errors,
     bit errors of erroneous frames, iterations, stop at max_frames / max_errors) is applied to those outcomes, and
@@ -143,9 +144,17 @@ def test_simulator_counters_match_oracle_decoded_blocks(family, gpu_device, orac
         beta = {k: float(v.item()) for k, v in dec.beta_weights.items()}
         alpha = {k: float(v.item()) for k, v in dec.alpha_weights.items()}
         cpu = lambda x: oracle_mod.neural2d(og, x, 2, 10, beta, alpha)
+    if staged:
+        # the streaming engine, blocks decoded in two stages (capped first stage + stragglers as a small batch: _decode_block);
+        # the cap comes from the previous block, so blocks 2.. of every point run staged wherever staging pays
+        from simulation_framework import _engine_of, _next_cap
+        eng = _engine_of(dec, gpu_device).set_mode("stream")
+        assert eng.info()["engine"] == "stream"
+        it = torch.cat([torch.full((900,), 3), torch.full((90,), 6), torch.full((10,), 10)]).to(torch.int32).to(gpu_device)
+        assert _next_cap(eng, it, 64) in (3, 4, 5, 6) and _next_cap(eng, torch.full((1000,), 10, dtype=torch.int32, device=gpu_device), 64) is None
     for snr_db, max_frames, max_errors, block in ((3.0, 2500, 30, 384), (1.0, 700, 1000, 200), (5.0, 1500, 5, 512)):
         cfg = SimulationConfig(max_frames=max_frames, max_errors=max_errors, batch_frames=block, seed=9,
-                               results_dir=str(tmp_path), save_results=False)
+                               results_dir=str(tmp_path), save_results=False, staged_early_stop=staged, stage_min_block=64)
         sim = LDPSimulator(cfg)
         with torch.no_grad():
             fer, ber, avg_it, _t, frames, errs = sim.simulate_single_snr(dec, code, snr_db, max_frames, max_errors)
