@@ -542,6 +542,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
     constexpr int JT = transpose_vars<T>();
     const GraphDev g = d->g->dev();
     const int T_it = capped_T(d);
+    const bool need_post = bits || posterior;          // packed decisions / iterations only: the last pass stores no posterior rows
     const int vc = (g.n + JT - 1) / JT;
     const dim3 tgrid((unsigned)((size_t)w.tiles * VEC * vc));       // transposes: one block per (tile, 64-codeword run, chunk)
 
@@ -664,7 +665,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
             for (int it = 0; it < T_it; ++it) {
                 int rc = (it == 0 && !q4) ? launch_cn<T, VEC>(d, w, 0, early_stop, s) : launch_cn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
-                rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s, /*store_posterior=*/true, rows)
+                rc = it == T_it - 1 ? launch_vn<T, VEC>(d, w, it, /*last=*/true, early_stop, s, /*store_posterior=*/need_post, rows)
                                     : launch_vn_q<VEC>(d, w, it, early_stop, s);
                 if (rc) return rc;
                 if (early_stop)
@@ -690,7 +691,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
                 if (early_stop || last) {
                     Workspace wv = w;
                     wv.c2v = buf[it & 1];
-                    rc = launch_vn<T, VEC>(d, wv, it, /*last=*/true, early_stop, s, /*store_posterior=*/last, last ? rows : nullptr);
+                    rc = launch_vn<T, VEC>(d, wv, it, /*last=*/true, early_stop, s, /*store_posterior=*/last && need_post, last ? rows : nullptr);
                     if (rc) return rc;
                 }
                 if (early_stop)
@@ -714,7 +715,7 @@ int decode_impl(const ldpc_decoder *d, const void *llr, int64_t batch, bool earl
         }
         int rc = launch_cn<T, VEC>(d, wc, it, early_stop, s);
         if (rc) return rc;
-        rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s, /*store_posterior=*/true, rows);
+        rc = launch_vn<T, VEC>(d, wv, it, it == T_it - 1, early_stop, s, /*store_posterior=*/it == T_it - 1 ? need_post : true, rows);
         if (rc) return rc;
         if (early_stop) {
             launch_syndrome<VEC>(g, w, it + 1, 1, s);

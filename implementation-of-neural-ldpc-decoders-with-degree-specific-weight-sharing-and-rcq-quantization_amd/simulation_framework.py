@@ -122,18 +122,36 @@ def _decode_block(eng, llr: torch.Tensor, cap):
     block runs in two stages: every codeword up to `cap` iterations (ldpc_decode_capped: the decoder's own per-iteration tables),
     then the few still open ones again from their LLRs as a small batch with the full iteration count.  A codeword's decode does
     not depend on its neighbours in the batch, and a codeword that stops within the cap stops at the same iteration with the
-    same decisions either way: the result is identical to the one-stage decode."""
+    same decisions either way: the result is identical to the one-stage decode.
+    The decisions come back bit-packed (uint8 [B, ceil(n/8)], the multi-GPU wire format): the driver only counts them, and the
+    engine then stores neither int32 decision rows nor posterior rows."""
+    kw = dict(early_stop=True, want_bits=False, want_posterior=False, want_packed=True)
     if cap is None:
-        res = eng.decode(llr, early_stop=True, want_posterior=False)
-        return res.bits, res.iterations
-    res = eng.decode(llr, early_stop=True, want_posterior=False, max_iters=int(cap))
-    bits, iters = res.bits, res.iterations
+        res = eng.decode(llr, **kw)
+        return res.packed_bits, res.iterations
+    res = eng.decode(llr, max_iters=int(cap), **kw)
+    packed, iters = res.packed_bits, res.iterations
     open_idx = torch.nonzero(~res.success, as_tuple=False).reshape(-1)
     if open_idx.numel():
-        rest = eng.decode(llr.index_select(0, open_idx).contiguous(), early_stop=True, want_posterior=False)
-        bits.index_copy_(0, open_idx, rest.bits)
+        rest = eng.decode(llr.index_select(0, open_idx).contiguous(), **kw)
+        packed.index_copy_(0, open_idx, rest.packed_bits)
         iters.index_copy_(0, open_idx, rest.iterations)
-    return bits, iters
+    return packed, iters
+
+
+_POPCOUNT = {}
+
+
+def _ones_per_frame(packed: torch.Tensor, n: int) -> torch.Tensor:
+    """number of set decision bits of every frame (int64 [B]) from the bit-packed rows"""
+    lut = _POPCOUNT.get(packed.device)
+    if lut is None:
+        lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.int16, device=packed.device)
+        _POPCOUNT[packed.device] = lut
+    if n % 8:                                       # bits past n in the last byte do not belong to the codeword
+        packed = packed.clone()
+        packed[:, -1] &= (1 << (n % 8)) - 1
+    return lut[packed.to(torch.int64)].sum(dim=1, dtype=torch.int64)
 
 
 def _next_cap(eng, iters: torch.Tensor, min_block: int = 1024):
@@ -187,10 +205,10 @@ class LDPSimulator:
         while total_frames < max_frames and frame_errors < max_errors:
             frames = min(block, max_frames - total_frames)
             llr = self._draw_llr(gen, frames, code.n, float(snr_db), device)
-            bits, iters = _decode_block(eng, llr, cap)
+            packed, iters = _decode_block(eng, llr, cap)
             cap = _next_cap(eng, iters, int(self.config.stage_min_block)) if self.config.staged_early_stop else None
-            wrong = bits != 0                                                   # all-zero codeword was sent
-            ferr = wrong.any(dim=1)
+            wrong = _ones_per_frame(packed, code.n)                             # all-zero codeword was sent: every 1 is an error
+            ferr = wrong > 0
             take = frames_to_count(ferr.cpu().numpy(), total_frames, frame_errors, max_frames, max_errors)
             frame_errors += int(ferr[:take].sum().item())
             bit_errors += int(wrong[:take].sum().item())

@@ -1167,6 +1167,14 @@ def test_capped_decode(early_stop, gpu_device, oracle_mod, engine_mode):
                 np.testing.assert_array_equal(part.iterations.cpu().numpy(), oi)
                 np.testing.assert_array_equal(part.success.cpu().numpy(), os_)
                 assert_post(part.posterior.cpu().numpy(), op)
+        # packed decisions only (what the Monte-Carlo driver asks for): no int32 rows, no posterior rows, same decisions
+        only = eng.decode(x, early_stop=early_stop, want_bits=False, want_posterior=False, want_packed=True)
+        both = eng.decode(x, early_stop=early_stop, want_packed=True)
+        assert only.bits is None and only.posterior is None
+        assert torch.equal(only.packed_bits, both.packed_bits) and torch.equal(only.iterations, full.iterations)
+        assert torch.equal(only.success, full.success)
+        unpacked = ((only.packed_bits.cpu().numpy()[:, :, None] >> np.arange(8)) & 1).reshape(len(llr), -1)[:, :code.n]
+        np.testing.assert_array_equal(unpacked, full.bits.cpu().numpy())
     with pytest.raises(Exception):
         engines["basic"].decode(x, max_iters=0)
 
