@@ -187,8 +187,9 @@ class LDPSimulator:
         noise_power = 1 / snr_linear
         z = torch.randn((frames, n), generator=gen, device=device, dtype=torch.float32)
         symbol = 1.0 if self.config.llr_convention == "decoder" else -1.0      # all-zero codeword
-        received = symbol + (noise_power ** 0.5) * z
-        return 2.0 * received / noise_power
+        # llr = 2 * (symbol + sigma * z) / sigma^2 (simulation_framework.py:95-103 of the reference), as ONE scale-and-shift in
+        # place: two passes over the block instead of four element-wise kernels with a temporary each
+        return z.mul_(2.0 * (noise_power ** 0.5) / noise_power).add_(2.0 * symbol / noise_power)
 
     def simulate_single_snr(self, decoder: Callable, code: LDPCCode, snr_db: float, max_frames: int,
                             max_errors: int) -> Tuple[float, float, float, float, int, int]:
