@@ -57,6 +57,30 @@ def test_result_container_and_json_layout(tmp_path):
     assert back.snr_values == [0.0, 0.5, 1.0]
 
 
+def test_error_counting_from_packed_decisions_and_stage_cap():
+    """host logic of the block decode: ones per frame from the bit-packed rows (bits past n ignored) and the choice of the
+    first stage's iteration cap from a block's stop iterations"""
+    from simulation_framework import _next_cap, _ones_per_frame
+    rng = np.random.default_rng(3)
+    for n in (96, 1998, 13):
+        bits = (rng.random((37, n)) < 0.3).astype(np.uint8)
+        padded = np.concatenate([bits, np.ones((37, (-n) % 8), np.uint8)], axis=1)          # garbage past n must not count
+        packed = np.packbits(padded, axis=1, bitorder="little")
+        got = _ones_per_frame(torch.from_numpy(packed), n)
+        np.testing.assert_array_equal(got.numpy(), bits.sum(axis=1))
+
+    class Eng:
+        iters = 20
+        def __init__(self, kind): self.kind = kind
+        def info(self): return {"engine": self.kind}
+    it = torch.cat([torch.full((3000,), 5), torch.full((900,), 7), torch.full((90,), 12), torch.full((10,), 20)]).to(torch.int32)
+    assert _next_cap(Eng("stream"), it) == 7                      # 7 + 0.025 * 22 beats 5 + 0.25 * 22 and 12 + 0.0025 * 22
+    assert _next_cap(Eng("resident"), it) is None                 # that engine stops codeword by codeword already
+    assert _next_cap(Eng("stream"), torch.full((4000,), 20, dtype=torch.int32)) is None       # nothing stops early
+    assert _next_cap(Eng("stream"), it[:500]) is None             # small blocks are not staged
+    assert _next_cap(Eng("stream"), it[:500], 64) is not None
+
+
 def test_create_test_decoders_matches_reference_set():
     from ldpc_decoder import create_test_ldpc_code
     from simulation_framework import create_test_decoders
